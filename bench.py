@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- RTF of the F5-TTS hot path (CFM.sample -> DiT x NFE -> Vocos) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one utterance through the whole path on every rank: sample() (text encoder, time/AdaLN precompute,
+NFE Euler steps with CFG over the DiT backbone) + Vocos decode of the generated frames, and for N > 1 one RCCL
+all_gather of the generated mel.  Workload (BASELINE.json configs[1], "C2"): F5-TTS Base, bf16 MFMA operands,
+batch 1, prompt 256 frames, total 1024 frames (768 generated = 8.192 s of 24 kHz audio), NFE=16 (EPSS grid),
+cfg_strength 2.0, sway -1; synthetic random-init weights (seed 0) and synthetic inputs, all resident in HBM before the
+timed region.  value = generated audio seconds of ALL ranks / wall seconds (the metric as BASELINE.json words it:
+audio_sec / wall_sec, higher is better); rtf_wall_over_audio (the reference's own convention, benchmark.py:457) is
+its inverse.  Scaling is weak: every rank synthesises its own utterance per step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--nfe", type=int, default=16)
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--ref-frames", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="Euler steps timed on the host for cpu_baseline")
+    return ap.parse_args()
+
+
+def dit_flops_per_seq_forward(N, D=1024, depth=22, F=2048, Dt=512, mel=100):
+    """algorithmic FLOPs of one sequence-forward of N tokens through DiT Base."""
+    per_block = 2 * N * D * 3 * D + 2 * N * D * D + 4 * N * N * D + 2 * 2 * N * D * F
+    embed = 2 * N * (2 * mel + Dt) * D + 2 * (2 * N * D * (D // 16) * 31) + 2 * N * D * mel
+    return depth * per_block + embed
+
+
+def make_inputs(P, args, rank):
+    g = torch.Generator().manual_seed(1 + rank)
+    B = args.batch
+    cond = torch.randn(B, args.ref_frames, 100, generator=g)
+    nt = round(0.15 * args.frames)
+    text = torch.randint(1, P.config.VOCAB_SIZE - 1, (B, nt), generator=g)
+    return cond, text
+
+
+def cpu_baseline(P, args, sd, vsd, cond, text):
+    """The CPU oracle (a port: the reference itself cannot travel to the GPU box) on a bounded sample of the same
+    workload: `cpu_steps` of the NFE Euler steps are timed and scaled (per-step cost does not depend on the step),
+    text encoder and Vocos decode are timed in full."""
+    from oracle import f5_oracle as O
+
+    arch = P.config.F5TTS_BASE
+    cores = torch.get_num_threads()
+    N = args.frames
+    gen = N - args.ref_frames
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=args.cpu_steps, cfg_strength=2.0,
+                          sway_sampling_coef=-1.0, seed=0, use_epss=False)
+        t1 = time.perf_counter()
+        one, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=1, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0,
+                          use_epss=False)
+        t2 = time.perf_counter()
+        O.vocos_decode(vsd, out[:, args.ref_frames:].permute(0, 2, 1))
+        t3 = time.perf_counter()
+    per_step = ((t1 - t0) - (t2 - t1)) / max(args.cpu_steps - 1, 1)
+    fixed = max((t2 - t1) - per_step, 0.0)
+    wall = fixed + per_step * args.nfe + (t3 - t2)
+    audio = gen * 256 / 24000
+    return {"value": audio / wall, "unit": "audio_sec/wall_sec", "cores": cores, "kind": "port",
+            "wall_sec_scaled": wall, "rtf_wall_over_audio": wall / audio,
+            "sample": f"CPU oracle (PyTorch fp32, {cores} threads) on the same utterance: {args.cpu_steps} of {args.nfe} "
+                      f"Euler steps timed ({per_step:.2f} s/step) and scaled to NFE={args.nfe}, plus text encoder "
+                      f"({fixed:.2f} s) and Vocos decode of {gen} frames ({t3 - t2:.2f} s) timed in full"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import f5_tts_amd as P
+
+    arch = P.config.F5TTS_BASE
+    nv = P.config.VOCAB_SIZE + 1  # load_model: text_num_embeds = vocab_size + 1 (utils_infer.py:313-317)
+    tr = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
+    model = P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(dev)
+    voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
+    cond_cpu, text_cpu = make_inputs(P, args, rank)
+    cond, text = cond_cpu.to(dev), text_cpu.to(dev)
+    eng = tr.engine()
+    eng.reserve(args.batch, args.frames, args.nfe)
+    N, ref, B = args.frames, args.ref_frames, args.batch
+    gen = N - ref
+    kw = dict(steps=args.nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
+    gather_buf = None
+    if world > 1:
+        gather_buf = torch.empty(world, B, gen, 100, device=dev)
+
+    def step():
+        out, _traj = model.sample(cond, text, N, **kw)
+        mel_gen = out[:, ref:, :]
+        wav = voc.decode(mel_gen.permute(0, 2, 1))
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, mel_gen.contiguous())
+        return out, wav
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, wav = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, wav = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all() and torch.isfinite(wav).all()
+
+    audio_per_step = B * gen * 256 / 24000
+    value = audio_per_step * args.steps * world / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    result = {
+        "metric": "RTF (audio_sec/wall_sec) F5-TTS Base NFE=%d batch=%d" % (args.nfe, B),
+        "value": value, "unit": "audio_sec/wall_sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "rtf_wall_over_audio": 1.0 / value * world,  # per-utterance RTF in the reference's convention (wall / audio)
+        "config": {"workload": "C2: F5-TTS Base, 1 utterance/rank/step, prompt %d + generated %d mel frames, NFE=%d EPSS, "
+                               "cfg 2.0, sway -1, Vocos decode, mel all_gather when n_gpus>1" % (ref, gen, args.nfe),
+                   "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
+                   "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel class (MFMA GEMMs), per-launch HIP events on the launch stream, in a
+        # dedicated pass over the same workload right after the timed region
+        if not args.no_profile:
+            eng.profile(True)
+            model.sample(cond, text, N, **kw)
+            torch.cuda.synchronize()
+            prof = eng.profile_read()
+            eng.profile(False)
+            gm, at = prof["gemm"], prof["attention"]
+            peak = MFMA_PEAK_TFLOPS[args.precision]
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            result["roofline"] = {
+                "bound": "mfma", "kernel": "gemm_tn_kernel (all DiT projections / FFN, fused epilogues)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
+                "flops_per_launch_avg": gm["flops"] / max(gm["launches"], 1),
+            }
+            result["kernel_classes"] = {
+                k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                    "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
+                for k, v in prof.items()}
+            total_fl = 2 * args.nfe * dit_flops_per_seq_forward(N) * B
+            result["whole_path_tflops"] = total_fl / (ms_per_step * 1e-3) / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(P, args, tr.state_dict(), voc.state_dict(), cond_cpu, text_cpu)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the bench line
+                result["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,9 +3,9 @@
 Host side = Python on PyTorch-ROCm (device memory, streams, torch.distributed); compute = hand-written HIP kernels
 for gfx950 in csrc/, reached through the C-ABI declared in include/f5_hip.h (ctypes, no torch types cross it).
 """
-from . import config, weights  # noqa: F401
+from . import config, mel, utils, weights  # noqa: F401
 
-__all__ = ["config", "weights", "CFM", "DiT", "UNetT", "Vocos", "lib"]
+__all__ = ["config", "weights", "mel", "utils", "CFM", "DiT", "UNetT", "Vocos", "lib"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require the built library (CPU-only tooling)

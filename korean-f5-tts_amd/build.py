@@ -1,0 +1,76 @@
+"""Builds libf5hip.so (the C-ABI engine, include/f5_hip.h) for gfx950 with hipcc, in-tree.
+
+    python korean-f5-tts_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to build/ (git-ignored); the .so lands next to this file so that it
+travels with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libf5hip.so")
+OBJDIR = os.path.join(ROOT, "build", "f5hip")
+SOURCES = ["engine.hip", "vocos.hip", "kapi.hip"]
+HEADERS = ["f5_common.h", "gemm.h", "attn.h", "convpos.h", "elementwise.h", "internal.h", "../../include/f5_hip.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(OBJDIR, "digest.txt")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = _hipcc()
+    t0 = time.time()
+    procs = []
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    if verbose:
+        print(f"built {LIB} in {time.time() - t0:.1f}s")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,219 @@
+// Non-causal flash attention for dim_head = 64 on gfx950 MFMA (reference: modules.py:499-508, torch SDPA backend).
+//
+// Inputs come from the fused QKV epilogue (gemm.h EpiQKV): Q (pre-scaled by 64^-0.5, rotary applied) and K as
+// [B', H, N, 64], V TRANSPOSED as [B', H, 64, Npad].  Output O as [B', N, H*64].
+//
+// Everything is computed transposed so that no LDS round trip or cross-lane shuffle is needed for P:
+//   S^T[key, q] = K . Q^T        MFMA(A = K fragment, B = Q fragment)   -> lane owns ONE q column (l & 15) and, per
+//                                16-key sub-tile, keys 4*(l>>4)..+3 in its 4 accumulator registers
+//   O^T[dh, q]  = V^T . P^T      MFMA(A = V^T fragment, B = P^T fragment): the B operand wants, per lane, k-values of
+//                                column q -- exactly what the S^T accumulators already are.  bf16: the 8 k-slots of a
+//                                32-key step are filled with keys {4g..4g+3} of two adjacent 16-key sub-tiles, and
+//                                the V^T fragment is read with the same key permutation (two 8-byte LDS reads).
+//                                f32 (16x16x4): step r of a 16-key sub-tile takes accumulator register r directly.
+// Softmax statistics are per q column = per lane: the running max needs two shuffles (xor 16, 32) per tile, the
+// rescale factor and the running sum are lane-local (partial sums are combined once at the end).
+//
+// Block = 4 waves x 32 q rows = 128 q rows of one (b', h); KV tiles of 64 keys, double-buffered in LDS with register
+// prefetch (one barrier per tile).  Keys >= kv_len (the sample's own length when the reference's attn_mask_enabled is
+// set, else N) are masked; K/V tiles beyond kv_len are never loaded.
+#pragma once
+#include "gemm.h"
+
+namespace f5 {
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                       const T* __restrict__ Vt, T* __restrict__ O, int H, int N,
+                                                       int Npad, const int* __restrict__ kv_lens, int nbatch_lens) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RB = 64 * sizeof(T);          // bytes per 64-element row (128 / 256)
+    constexpr int RS = RB + 16;                 // padded LDS row stride
+    constexpr int NF = RB / 64;                 // 16-byte fragments per lane per 64-element row (2 / 4)
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int CH = 64 * (RB / 16) / 256;    // 16-byte chunks per thread per tile (2 / 4)
+    constexpr int TILE = 64 * RS;
+    constexpr int BUF = 2 * TILE;
+    constexpr float L2E = 1.4426950408889634f;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * H + h;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    int kv_len = N;
+    if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
+    const int nkt = (kv_len + 63) / 64;
+
+    // Q fragments stay in registers for the whole kernel
+    u32x4 qf[2][NF];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int q = q0 + qs * 16 + l15;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            qf[qs][f] = q < N ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Q + (bh * N + q) * 64) +
+                                                                f * 64 + g * 16)
+                              : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    u32x4 rk[CH], rv[CH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * 256, row = c / (RB / 16), cc = c % (RB / 16);
+            const int key = kt * 64 + row;
+            rk[i] = key < N ? *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * EPC) : u32x4{0u, 0u, 0u, 0u};
+            rv[i] = *reinterpret_cast<const u32x4*>(Vt + (bh * 64 + row) * Npad + kt * 64 + cc * EPC);
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * 256, row = c / (RB / 16), cc = c % (RB / 16);
+            *reinterpret_cast<u32x4*>(base + row * RS + cc * 16) = rk[i];
+            *reinterpret_cast<u32x4*>(base + TILE + row * RS + cc * 16) = rv[i];
+        }
+    };
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const char* Ks = smem + (kt & 1) * BUF + l15 * RS + g * 16;
+        const char* Vs = smem + (kt & 1) * BUF + TILE + l15 * RS;
+
+        // ---- S^T = K Q^T
+        f32x4 s[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + ks * 16 * RS + f * 64);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<T>::run(kf, qf[qs][f], s[ks][qs]);
+            }
+        }
+
+        // ---- online softmax (per q column = per lane)
+        const int key_base = kt * 64 + g * 4;
+        const bool edge = (kt * 64 + 64 > kv_len);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mloc = -1e30f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (edge && key_base + ks * 16 + r >= kv_len) s[ks][qs][r] = -1e30f;
+                    mloc = fmaxf(mloc, s[ks][qs][r]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mnew = fmaxf(mrun[qs], mloc);
+            const float alpha = exp2f((mrun[qs] - mnew) * L2E);
+            mrun[qs] = mnew;
+            const float mb = mnew * L2E;
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = exp2f(s[ks][qs][r] * L2E - mb);
+                    if (edge && key_base + ks * 16 + r >= kv_len) p = 0.f;
+                    s[ks][qs][r] = p;
+                    psum += p;
+                }
+            lrun[qs] = lrun[qs] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha;
+            }
+        }
+
+        // ---- O^T += V^T P^T
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                u32x4 pf[2];
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    bf16x8 pv = {(bf16_t)s[2 * kp][qs][0],     (bf16_t)s[2 * kp][qs][1],     (bf16_t)s[2 * kp][qs][2],
+                                 (bf16_t)s[2 * kp][qs][3],     (bf16_t)s[2 * kp + 1][qs][0], (bf16_t)s[2 * kp + 1][qs][1],
+                                 (bf16_t)s[2 * kp + 1][qs][2], (bf16_t)s[2 * kp + 1][qs][3]};
+                    pf[qs] = __builtin_bit_cast(u32x4, pv);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* vrow = Vs + dt * 16 * RS + (32 * kp + 4 * g) * 2;
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 32);
+                    const u32x4 vf = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<T>::run(vf, pf[qs], o[dt][qs]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(Vs + dt * 16 * RS + (16 * ks + 4 * g) * 4);
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs)
+                        o[dt][qs] = Mma<T>::run(vf, __builtin_bit_cast(u32x4, s[ks][qs]), o[dt][qs]);
+                }
+            }
+        }
+
+        if (kt + 1 < nkt) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store O[b, q, h*64 + dh]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qs * 16 + l15;
+        if (q < N) {
+            T* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                store4(dst + dt * 16, o[dt][qs][0] * inv, o[dt][qs][1] * inv, o[dt][qs][2] * inv, o[dt][qs][3] * inv);
+        }
+    }
+}
+
+template <typename T>
+inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H, int N,
+                                   int Npad, const int* kv_lens, int nbatch_lens) {
+    constexpr int smem = 2 * 2 * 64 * (64 * (int)sizeof(T) + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((N + 127) / 128, H, Bp);
+    hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens);
+    return hipGetLastError();
+}
+
+}  // namespace f5

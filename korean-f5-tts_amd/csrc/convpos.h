@@ -1,0 +1,149 @@
+// Grouped Conv1d(k=31, groups=16, same padding) + Mish as an implicit GEMM on MFMA -- the reference's
+// ConvPositionEmbedding (modules.py:170-196) in token-major layout, no [B,D,N] permute.
+//
+//   Y[b, n, co] = mish( bias[co] + sum_{tap<31} sum_{ci<CPG} Wp[co][tap*CPG + ci] * X[b, n + tap - 15, g*CPG + ci] )  (+ res)
+//
+// One block = one (batch row, group, 128-token tile).  The block's input window (128 + 30 halo tokens x CPG channels)
+// is converted to the MFMA operand type and kept in LDS for all 31 taps; the packed weights Wp[co][31*CPG] (engine
+// repacks torch's [co][ci][tap] at load time) stream through a double-buffered LDS tile exactly like gemm.h's W operand.
+// The im2col row of a token is never materialised: the fragment for k-chunk (tap, ci0) of token t is simply the
+// 16 bytes at LDS row (t + tap), column ci0.
+// Masking (batched inference, modules.py:187-192): tokens >= lens[b] read as zero and produce zero.
+#pragma once
+#include "gemm.h"
+
+namespace f5 {
+
+template <typename T, int CPG>
+__global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ X, const T* __restrict__ Wp, int Kp,
+                                                      const float* __restrict__ bias, const float* __restrict__ res,
+                                                      float* __restrict__ Y, int N, int D, const int* __restrict__ lens,
+                                                      int nbatch_lens) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 128;
+    constexpr int XR = TM + 32;                       // rows of the input window kept in LDS
+    constexpr int XRB = CPG * sizeof(T);              // bytes per window row
+    constexpr int XRS = XRB + 16;
+    constexpr int KT = GEMM_ROW_BYTES / sizeof(T);    // k elements per weight tile (128 bytes)
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int NJ = CPG / 16;
+    constexpr int WCH = (CPG * 8 + 255) / 256;
+    constexpr int WBUF = CPG * GEMM_ROW_STRIDE;
+    char* xs = smem;
+    char* ws = smem + XR * XRS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int tok0 = blockIdx.x * TM, grp = blockIdx.y, b = blockIdx.z;
+    const int len = lens ? min(N, lens[b % nbatch_lens]) : N;
+    const int nkt = (Kp + KT - 1) / KT;
+
+    // ---- stage the input window (fp32 -> T)
+    for (int c = tid; c < XR * (CPG / 4); c += 256) {
+        const int row = c / (CPG / 4), c4 = c % (CPG / 4);
+        const int tok = tok0 - 15 + row;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (tok >= 0 && tok < len) v = *reinterpret_cast<const float4*>(X + ((size_t)b * N + tok) * D + grp * CPG + c4 * 4);
+        store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, v.x, v.y, v.z, v.w);
+    }
+
+    u32x4 rw[WCH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * 256, row = c >> 3, cc = c & 7;
+            const int ke = kt * KT + cc * EPC;
+            rw[i] = (c < CPG * 8 && ke < Kp)
+                        ? *reinterpret_cast<const u32x4*>(Wp + (size_t)(grp * CPG + row) * Kp + ke)
+                        : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + i * 256, row = c >> 3, cc = c & 7;
+            if (c < CPG * 8) *reinterpret_cast<u32x4*>(ws + buf * WBUF + row * GEMM_ROW_STRIDE + cc * 16) = rw[i];
+        }
+    };
+
+    f32x4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const char* Ws = ws + (kt & 1) * WBUF + l15 * GEMM_ROW_STRIDE + g * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // im2col k index of this lane's 16-byte chunk -> (tap, ci0)
+            const int kidx = kt * KT + kk * (KT / 2) + g * EPC;
+            const int tap = kidx / CPG, ci0 = kidx - tap * CPG;
+            u32x4 xf[2], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                xf[i] = *reinterpret_cast<const u32x4*>(xs + (wave * 32 + i * 16 + l15 + tap) * XRS + ci0 * sizeof(T));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const u32x4*>(Ws + j * 16 * GEMM_ROW_STRIDE + kk * 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        }
+        if (kt + 1 < nkt) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tok = tok0 + wave * 32 + i * 16 + l15;
+        if (tok >= N) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co = grp * CPG + j * 16 + g * 4;
+            const float4 bi = *reinterpret_cast<const float4*>(bias + co);
+            float4 v = make_float4(acc[i][j][0] + bi.x, acc[i][j][1] + bi.y, acc[i][j][2] + bi.z, acc[i][j][3] + bi.w);
+            if (tok >= len) v = make_float4(0, 0, 0, 0);
+            v.x = mish(v.x); v.y = mish(v.y); v.z = mish(v.z); v.w = mish(v.w);
+            const size_t off = ((size_t)b * N + tok) * D + co;
+            if (res) {
+                const float4 r = *reinterpret_cast<const float4*>(res + off);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            *reinterpret_cast<float4*>(Y + off) = v;
+        }
+    }
+}
+
+template <typename T, int CPG>
+inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
+                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+    constexpr int smem = (128 + 32) * (CPG * (int)sizeof(T) + 16) + 2 * CPG * GEMM_ROW_STRIDE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((N + 127) / 128, D / CPG, Bp);
+    hipLaunchKernelGGL((convpos_kernel<T, CPG>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl);
+    return hipGetLastError();
+}
+
+// D/16 channels per group must be 16, 32 or 64 (dim 256 / 512 / 1024).
+template <typename T>
+inline hipError_t launch_convpos(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias, const float* res,
+                                 float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+    switch (D / 16) {
+        case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+        case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+        case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace f5

@@ -1,0 +1,847 @@
+// libf5hip.so -- engine + C ABI (include/f5_hip.h) for the F5-TTS inference hot path on MI355X / gfx950.
+//
+// Data layout in HBM (everything token-major, one arena per engine, sized for the largest (batch, frames) seen):
+//   ODE state y, step_cond, pred     f32 [B | 2B, N, mel]
+//   residual stream x, embed h, c1   f32 [2B*N, D]
+//   xn (LN-modulated), attn out, ffh T   [2B*N, D | inner | F]          T = bf16 (speed) or f32 (parity)
+//   q, k                             T   [2B, H, N, 64]      v^T  T [2B, H, 64, Npad]
+//   mod                              f32 [steps, (6*depth + 2) * D]     all AdaLN vectors of all layers for ALL steps
+// Weights are engine-owned copies: GEMM operands in T ([out, in], K padded to 16 bytes), everything that feeds
+// fp32-only stages (time MLP, AdaLN stack, text encoder, norms, biases) in f32.
+//
+// What is restructured w.r.t. the reference (results identical up to fp rounding):
+//   * AdaLN / time-embedding work depends only on t, not on x: it is hoisted out of the ODE loop and computed for all
+//     NFE steps by three GEMMs before the first step (the reference recomputes 22 x [D -> 6D] per forward).
+//   * q/k/v projections are one fused GEMM whose epilogue applies bias, rotary, the softmax scale and the head split.
+//   * gate * f(x) + residual and the padded-row mask are GEMM epilogues; GELU is an epilogue; no [B,D,N] permutes.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+#include "attn.h"
+#include "convpos.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+using namespace f5;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+int f5_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define fail f5_fail
+
+extern "C" const char* f5_last_error(void) { return g_err; }
+extern "C" const char* f5_version(void) { return "f5hip 1 gfx950"; }
+
+// ------------------------------------------------------------------------------------------- containers
+struct Tensor {
+    float* p = nullptr;
+    std::vector<int64_t> shape;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto s : shape) n *= (size_t)s;
+        return n;
+    }
+};
+
+struct WeightStore {
+    std::map<std::string, Tensor> t;
+    ~WeightStore() {
+        for (auto& kv : t)
+            if (kv.second.p) (void)hipFree(kv.second.p);
+    }
+    int put(const char* name, const void* dev, const int64_t* shape, int ndim, hipStream_t s) {
+        if (!name || !dev || ndim < 0 || ndim > 4) return fail(F5_EINVAL, "f5_load_weight: bad arguments");
+        Tensor T;
+        T.shape.assign(shape, shape + ndim);
+        const size_t bytes = T.numel() * sizeof(float);
+        auto it = t.find(name);
+        if (it != t.end()) {
+            (void)hipFree(it->second.p);
+            t.erase(it);
+        }
+        HIPCHK(hipMalloc((void**)&T.p, bytes ? bytes : 4));
+        HIPCHK(hipMemcpyAsync(T.p, dev, bytes, hipMemcpyDeviceToDevice, s));
+        t[name] = T;
+        return F5_OK;
+    }
+    const Tensor* get(const std::string& n) const {
+        auto it = t.find(n);
+        return it == t.end() ? nullptr : &it->second;
+    }
+};
+
+// per-launch HIP-event profiler (off by default): one (start, stop) event pair per bracket on the launch stream
+struct Prof {
+    enum { MAXEV = 65536 };
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    std::vector<double> flops;
+    int used = 0;
+    ~Prof() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    void clear() {
+        used = 0;
+        cls.clear();
+        flops.clear();
+    }
+    void begin(int c, hipStream_t s, double fl = 0.0) {
+        if (!on || used + 2 > MAXEV) return;
+        while ((int)ev.size() < used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ev.push_back(e);
+        }
+        (void)hipEventRecord(ev[used], s);
+        cls.push_back(c);
+        flops.push_back(fl);
+    }
+    void end(hipStream_t s) {
+        if (!on || used + 2 > MAXEV || (int)ev.size() < used + 2 || (int)cls.size() * 2 != used + 2) return;
+        (void)hipEventRecord(ev[used + 1], s);
+        used += 2;
+    }
+};
+enum { PC_GEMM = 0, PC_ATTN = 1, PC_LN = 2, PC_CONV = 3, PC_MISC = 4, PC_TEXT = 5, PC_TIME = 6 };
+
+// Host staging (pinned) for small per-call scalars: time grid, lengths.
+struct Staging {
+    char* host = nullptr;
+    size_t cap = 0;
+    ~Staging() {
+        if (host) (void)hipHostFree(host);
+    }
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return F5_OK;
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
+        cap = 0;
+        HIPCHK(hipHostMalloc((void**)&host, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return F5_OK;
+    }
+};
+
+// --------------------------------------------------------------------------------------- packed weights
+template <typename T> struct LinW {
+    T* w = nullptr;      // [N, ldw]
+    float* b = nullptr;  // [N] or null
+    int N = 0, K = 0, ldw = 0;
+};
+
+template <typename T> struct BlockW {
+    LinW<T> qkv, out, ff1, ff2, skip;  // skip: UNetT concat projection (no bias)
+    float* norm1_g = nullptr;          // UNetT RMSNorm gains
+    float* norm2_g = nullptr;
+};
+
+struct TextBlockW {
+    float *dwk = nullptr, *dwb = nullptr, *lnw = nullptr, *lnb = nullptr, *gamma = nullptr, *beta = nullptr;
+    LinW<float> pw1, pw2;
+};
+
+template <typename T> struct Packed {
+    LinW<float> time0, time2, mod;  // mod: stacked AdaLN linears [(6*depth+2)*D, D]
+    float* E = nullptr;             // text embedding table
+    std::vector<TextBlockW> tblocks;
+    LinW<T> in_proj;
+    T* conv_w[2] = {nullptr, nullptr};
+    float* conv_b[2] = {nullptr, nullptr};
+    int conv_kp = 0;
+    std::vector<BlockW<T>> blocks;
+    LinW<T> proj_out;
+    float* norm_out_g = nullptr;  // UNetT
+    // aux tables
+    float *rope_cos = nullptr, *rope_sin = nullptr, *time_freqs = nullptr, *text_pos = nullptr;
+    int text_pos_rows = 0;
+};
+
+struct f5_engine {
+    f5_config cfg{};
+    int inner = 0, kin = 0, kin_pad = 0, modN = 0;
+    WeightStore ws;
+    std::vector<void*> owned;  // packed buffers
+    Packed<float> pf;
+    Packed<bf16_t> pb;
+    bool finalized = false;
+    Arena arena;
+    Staging stage;
+    Prof prof;
+    int res_B = 0, res_N = 0, res_S = 0;
+    ~f5_engine() {
+        for (void* p : owned) (void)hipFree(p);
+    }
+};
+
+template <typename U> static int dev_alloc(f5_engine* e, U** out, size_t n) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n * sizeof(U), 16)));
+    e->owned.push_back(p);
+    *out = reinterpret_cast<U*>(p);
+    return F5_OK;
+}
+
+// ----------------------------------------------------------------------------------------------- create
+extern "C" int f5_create(const f5_config* c, f5_engine** out) {
+    if (!c || !out) return fail(F5_EINVAL, "f5_create: null argument");
+    if (c->dim_head != 64) return fail(F5_EINVAL, "dim_head must be 64 (got %d)", c->dim_head);
+    if (c->dim % 256 != 0 || (c->dim / 16 != 16 && c->dim / 16 != 32 && c->dim / 16 != 64))
+        return fail(F5_EINVAL, "dim must be 256, 512 or 1024 (got %d)", c->dim);
+    if (c->heads <= 0 || (c->heads * 64) % 64 != 0 || c->depth <= 0) return fail(F5_EINVAL, "bad heads/depth");
+    if (c->mel_dim % 4 || c->text_dim % 4 || c->ff_dim % 8) return fail(F5_EINVAL, "mel_dim/text_dim %% 4, ff_dim %% 8 required");
+    if ((2 * c->mel_dim + c->text_dim) % 4) return fail(F5_EINVAL, "2*mel_dim + text_dim must be a multiple of 4");
+    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16) return fail(F5_EINVAL, "bad precision");
+    if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return fail(F5_EINVAL, "bad backbone");
+    if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2)) return fail(F5_EINVAL, "UNetT depth must be even");
+    if (c->text_dim > 2048 || c->dim > 2048) return fail(F5_EINVAL, "dims > 2048 unsupported");
+    f5_engine* e = new f5_engine();
+    e->cfg = *c;
+    e->inner = c->heads * 64;
+    e->kin = 2 * c->mel_dim + c->text_dim;
+    e->kin_pad = round_up(e->kin, 8);
+    e->modN = (6 * c->depth + 2) * c->dim;
+    *out = e;
+    return F5_OK;
+}
+extern "C" int f5_destroy(f5_engine* e) {
+    if (e) {
+        (void)hipDeviceSynchronize();
+        delete e;
+    }
+    return F5_OK;
+}
+extern "C" int f5_load_weight(f5_engine* e, const char* name, const void* dev, const int64_t* shape, int32_t ndim,
+                              f5_stream stream) {
+    if (!e) return fail(F5_EINVAL, "null engine");
+    e->finalized = false;
+    return e->ws.put(name, dev, shape, ndim, (hipStream_t)stream);
+}
+
+// --------------------------------------------------------------------------------------------- finalize
+static int need(const WeightStore& ws, const std::string& n, std::initializer_list<int64_t> shape, const Tensor** out) {
+    const Tensor* t = ws.get(n);
+    if (!t) return fail(F5_ESTATE, "missing weight '%s'", n.c_str());
+    std::vector<int64_t> want(shape);
+    if (t->shape != want) {
+        std::string got, exp;
+        for (auto s : t->shape) got += std::to_string(s) + ",";
+        for (auto s : want) exp += std::to_string(s) + ",";
+        return fail(F5_EINVAL, "weight '%s' has shape [%s], expected [%s]", n.c_str(), got.c_str(), exp.c_str());
+    }
+    *out = t;
+    return F5_OK;
+}
+
+// W [N, K] f32 -> T [N, round_up(K, 8)]
+template <typename T>
+static int pack_linear(f5_engine* e, hipStream_t s, const std::string& wname, const std::string& bname, int N, int K,
+                       LinW<T>* L, int n_pad = 0) {
+    const Tensor *w = nullptr, *b = nullptr;
+    CHK(need(e->ws, wname, {N, K}, &w));
+    const int Np = n_pad ? n_pad : N;
+    L->N = Np;
+    L->K = K;
+    L->ldw = round_up(K, 8);
+    CHK(dev_alloc(e, &L->w, (size_t)Np * L->ldw));
+    hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)Np * L->ldw)), dim3(256), 0, s, w->p, K, N, K, L->w,
+                       L->ldw, Np);
+    L->b = nullptr;
+    if (!bname.empty()) {
+        CHK(need(e->ws, bname, {N}, &b));
+        CHK(dev_alloc(e, &L->b, (size_t)Np));
+        hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(ew_blocks(Np)), dim3(256), 0, s, b->p, N, 1, N, L->b, Np, 1);
+    }
+    HIPCHK(hipGetLastError());
+    return F5_OK;
+}
+
+// concatenates several [Ni, K] linears row-wise into one [sum Ni, ldw] operand (+ bias)
+template <typename T>
+static int pack_concat(f5_engine* e, hipStream_t s, const std::vector<std::string>& pfx, int Ni, int K, LinW<T>* L,
+                       bool bias = true) {
+    const int n = (int)pfx.size();
+    L->N = n * Ni;
+    L->K = K;
+    L->ldw = round_up(K, 8);
+    CHK(dev_alloc(e, &L->w, (size_t)L->N * L->ldw));
+    L->b = nullptr;
+    if (bias) CHK(dev_alloc(e, &L->b, (size_t)L->N));
+    for (int i = 0; i < n; ++i) {
+        const Tensor *w = nullptr, *b = nullptr;
+        CHK(need(e->ws, pfx[i] + ".weight", {Ni, K}, &w));
+        hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)Ni * L->ldw)), dim3(256), 0, s, w->p, K, Ni, K,
+                           L->w + (size_t)i * Ni * L->ldw, L->ldw, Ni);
+        if (bias) {
+            CHK(need(e->ws, pfx[i] + ".bias", {Ni}, &b));
+            HIPCHK(hipMemcpyAsync(L->b + (size_t)i * Ni, b->p, (size_t)Ni * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return F5_OK;
+}
+
+static int copy_vec(f5_engine* e, hipStream_t s, const std::string& name, std::initializer_list<int64_t> shape,
+                    float** out) {
+    const Tensor* t = nullptr;
+    CHK(need(e->ws, name, shape, &t));
+    CHK(dev_alloc(e, out, t->numel()));
+    HIPCHK(hipMemcpyAsync(*out, t->p, t->numel() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return F5_OK;
+}
+
+template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStream_t s) {
+    const f5_config& c = e->cfg;
+    const int D = c.dim, Dt = c.text_dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim;
+    const bool dit = c.backbone == F5_BACKBONE_DIT;
+    // aux tables
+    const Tensor* t = nullptr;
+    if (!(t = e->ws.get("aux.rope_cos")) || t->shape.size() != 2 || t->shape[1] != 32 || t->shape[0] < 1)
+        return fail(F5_ESTATE, "missing/invalid aux.rope_cos [max_pos, 32]");
+    const int64_t maxpos = t->shape[0];
+    e->cfg.max_pos = (int)maxpos;
+    CHK(copy_vec(e, s, "aux.rope_cos", {maxpos, 32}, &P.rope_cos));
+    CHK(copy_vec(e, s, "aux.rope_sin", {maxpos, 32}, &P.rope_sin));
+    CHK(copy_vec(e, s, "aux.time_freqs", {128}, &P.time_freqs));
+    // time MLP
+    CHK(pack_linear<float>(e, s, "time_embed.time_mlp.0.weight", "time_embed.time_mlp.0.bias", D, 256, &P.time0));
+    CHK(pack_linear<float>(e, s, "time_embed.time_mlp.2.weight", "time_embed.time_mlp.2.bias", D, D, &P.time2));
+    // text encoder
+    CHK(copy_vec(e, s, "text_embed.text_embed.weight", {c.text_num_embeds + 1, Dt}, &P.E));
+    if (c.conv_layers > 0) {
+        if (!(t = e->ws.get("aux.text_pos")) || t->shape.size() != 2 || t->shape[1] != Dt)
+            return fail(F5_ESTATE, "missing/invalid aux.text_pos [P, text_dim]");
+        P.text_pos_rows = (int)t->shape[0];
+        CHK(copy_vec(e, s, "aux.text_pos", {t->shape[0], Dt}, &P.text_pos));
+    }
+    P.tblocks.resize(c.conv_layers);
+    for (int i = 0; i < c.conv_layers; ++i) {
+        const std::string p = "text_embed.text_blocks." + std::to_string(i);
+        TextBlockW& tb = P.tblocks[i];
+        const Tensor* dw = nullptr;
+        CHK(need(e->ws, p + ".dwconv.weight", {Dt, 1, 7}, &dw));
+        CHK(dev_alloc(e, &tb.dwk, (size_t)7 * Dt));
+        hipLaunchKernelGGL((permute_last2_kernel<float>), dim3(ew_blocks(7L * Dt)), dim3(256), 0, s, dw->p, tb.dwk, 1L, Dt, 7);
+        CHK(copy_vec(e, s, p + ".dwconv.bias", {Dt}, &tb.dwb));
+        CHK(copy_vec(e, s, p + ".norm.weight", {Dt}, &tb.lnw));
+        CHK(copy_vec(e, s, p + ".norm.bias", {Dt}, &tb.lnb));
+        CHK(copy_vec(e, s, p + ".grn.gamma", {1, 1, 2 * Dt}, &tb.gamma));
+        CHK(copy_vec(e, s, p + ".grn.beta", {1, 1, 2 * Dt}, &tb.beta));
+        CHK(pack_linear<float>(e, s, p + ".pwconv1.weight", p + ".pwconv1.bias", 2 * Dt, Dt, &tb.pw1));
+        CHK(pack_linear<float>(e, s, p + ".pwconv2.weight", p + ".pwconv2.bias", Dt, 2 * Dt, &tb.pw2));
+    }
+    // input embedding
+    CHK(pack_linear<T>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj));
+    const int cpg = D / 16;
+    P.conv_kp = 31 * cpg;
+    for (int j = 0; j < 2; ++j) {
+        const std::string p = "input_embed.conv_pos_embed.conv1d." + std::to_string(j * 2);
+        const Tensor* w = nullptr;
+        CHK(need(e->ws, p + ".weight", {D, cpg, 31}, &w));
+        CHK(dev_alloc(e, &P.conv_w[j], (size_t)D * P.conv_kp));
+        hipLaunchKernelGGL((permute_last2_kernel<T>), dim3(ew_blocks((long)D * P.conv_kp)), dim3(256), 0, s, w->p,
+                           P.conv_w[j], (long)D, cpg, 31);
+        CHK(copy_vec(e, s, p + ".bias", {D}, &P.conv_b[j]));
+    }
+    // transformer
+    P.blocks.resize(c.depth);
+    std::vector<std::string> modp;
+    for (int i = 0; i < c.depth; ++i) {
+        BlockW<T>& b = P.blocks[i];
+        const std::string p = dit ? "transformer_blocks." + std::to_string(i) : "layers." + std::to_string(i);
+        const std::string at = dit ? p + ".attn" : p + ".2";
+        const std::string ff = dit ? p + ".ff" : p + ".4";
+        CHK(pack_concat<T>(e, s, {at + ".to_q", at + ".to_k", at + ".to_v"}, inner, D, &b.qkv));
+        CHK(pack_linear<T>(e, s, at + ".to_out.0.weight", at + ".to_out.0.bias", D, inner, &b.out));
+        CHK(pack_linear<T>(e, s, ff + ".ff.0.0.weight", ff + ".ff.0.0.bias", F, D, &b.ff1));
+        CHK(pack_linear<T>(e, s, ff + ".ff.2.weight", ff + ".ff.2.bias", D, F, &b.ff2));
+        if (dit) {
+            modp.push_back(p + ".attn_norm.linear");
+        } else {
+            CHK(copy_vec(e, s, p + ".1.g", {D}, &b.norm1_g));
+            CHK(copy_vec(e, s, p + ".3.g", {D}, &b.norm2_g));
+            if (i >= c.depth / 2 && e->ws.get(p + ".0.weight"))
+                CHK(pack_linear<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
+        }
+    }
+    if (dit) {
+        // stacked AdaLN: rows [l*6D, (l+1)*6D) = layer l (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp);
+        // last 2D rows = norm_out (scale, shift).  Always f32.
+        LinW<float>& M = P.mod;
+        M.N = e->modN;
+        M.K = D;
+        M.ldw = D;
+        CHK(dev_alloc(e, &M.w, (size_t)M.N * D));
+        CHK(dev_alloc(e, &M.b, (size_t)M.N));
+        for (int i = 0; i <= c.depth; ++i) {
+            const bool last = i == c.depth;
+            const std::string p = last ? std::string("norm_out.linear") : modp[i];
+            const int rows = last ? 2 * D : 6 * D;
+            const Tensor *w = nullptr, *b = nullptr;
+            CHK(need(e->ws, p + ".weight", {rows, D}, &w));
+            CHK(need(e->ws, p + ".bias", {rows}, &b));
+            HIPCHK(hipMemcpyAsync(M.w + (size_t)i * 6 * D * D, w->p, (size_t)rows * D * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(M.b + (size_t)i * 6 * D, b->p, (size_t)rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    } else {
+        CHK(copy_vec(e, s, "norm_out.g", {D}, &P.norm_out_g));
+    }
+    CHK(pack_linear<T>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out));
+    HIPCHK(hipGetLastError());
+    return F5_OK;
+}
+
+extern "C" int f5_finalize(f5_engine* e, f5_stream stream) {
+    if (!e) return fail(F5_EINVAL, "null engine");
+    hipStream_t s = (hipStream_t)stream;
+    for (void* p : e->owned) (void)hipFree(p);
+    e->owned.clear();
+    e->pf = Packed<float>();
+    e->pb = Packed<bf16_t>();
+    int r = e->cfg.precision == F5_PREC_BF16 ? finalize_t<bf16_t>(e, e->pb, s) : finalize_t<float>(e, e->pf, s);
+    if (r != F5_OK) return r;
+    HIPCHK(hipStreamSynchronize(s));
+    // the raw fp32 copies are no longer needed
+    for (auto& kv : e->ws.t) {
+        if (kv.second.p) (void)hipFree(kv.second.p);
+        kv.second.p = nullptr;
+    }
+    e->ws.t.clear();
+    e->finalized = true;
+    return F5_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- workspace
+template <typename T> struct Work {
+    // per call
+    float *tdev, *feat, *th, *temb, *st, *mod;
+    int* lens;
+    float *step_cond, *text_c, *text_u, *tx_a, *tx_b, *tx_h1, *grn_part;
+    unsigned char* dummy;
+    // per forward
+    T* acat;
+    float *h, *c1, *x, *pred;
+    T *xn, *q, *k, *vt, *ao, *ffh;
+    T* cat2;       // UNetT concat buffer [rows, 2D]
+    float* skips;  // UNetT skip stack
+    int Npad;
+};
+
+template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Work<T>& w, int B, int N, int S) {
+    const f5_config& c = e->cfg;
+    a.reset();
+    const size_t Bp = 2 * (size_t)B, D = c.dim, Dt = c.text_dim, F = c.ff_dim, mel = c.mel_dim;
+    const size_t Nt = c.backbone == F5_BACKBONE_UNETT ? N + 1 : N;  // UNetT prepends the time token
+    const size_t rows = Bp * Nt;
+    const size_t SS = (size_t)std::max(S + 1, (int)Bp + 1);
+    w.Npad = round_up((int)Nt, 64);
+    w.tdev = a.take<float>(SS);
+    w.feat = a.take<float>(SS * 256);
+    w.th = a.take<float>(SS * D);
+    w.temb = a.take<float>(SS * D);
+    w.st = a.take<float>(SS * D);
+    w.mod = a.take<float>(SS * e->modN);
+    w.lens = a.take<int>(Bp + 16);
+    w.step_cond = a.take<float>((size_t)B * N * mel);
+    w.text_c = a.take<float>((size_t)B * N * Dt);
+    w.text_u = a.take<float>((size_t)B * N * Dt);
+    w.tx_a = a.take<float>((size_t)B * N * Dt);
+    w.tx_b = a.take<float>((size_t)B * N * Dt);
+    w.tx_h1 = a.take<float>((size_t)B * N * 2 * Dt);
+    w.grn_part = a.take<float>((size_t)B * GRN_P * 2 * Dt);
+    w.acat = a.take<T>(Bp * N * e->kin_pad);
+    w.h = a.take<float>(rows * D);
+    w.c1 = a.take<float>(rows * D);
+    w.x = a.take<float>(rows * D);
+    w.pred = a.take<float>(Bp * N * mel);
+    w.xn = a.take<T>(rows * D);
+    w.q = a.take<T>(rows * e->inner);
+    w.k = a.take<T>(rows * e->inner);
+    w.ao = a.take<T>(rows * e->inner);
+    w.vt = a.take<T>(Bp * c.heads * 64 * w.Npad);
+    w.ffh = a.take<T>(rows * F);
+    w.cat2 = nullptr;
+    w.skips = nullptr;
+    if (c.backbone == F5_BACKBONE_UNETT) {
+        w.cat2 = a.take<T>(rows * 2 * D);
+        w.skips = a.take<float>(rows * D * (c.depth / 2));
+    }
+    return align_up(a.off, 256) + 256;
+}
+
+static size_t plan_bytes(const f5_engine* e, int B, int N, int S) {
+    Arena dry;  // base == nullptr: measures only
+    if (e->cfg.precision == F5_PREC_BF16) {
+        Work<bf16_t> w;
+        return carve_into<bf16_t>(e, dry, w, B, N, S);
+    }
+    Work<float> w;
+    return carve_into<float>(e, dry, w, B, N, S);
+}
+
+static int ensure_arena(f5_engine* e, int B, int N, int S) {
+    B = std::max(B, e->res_B); N = std::max(N, e->res_N); S = std::max(S, e->res_S);
+    const size_t need_b = plan_bytes(e, B, N, S);
+    if (need_b > e->arena.cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (e->arena.base) (void)hipFree(e->arena.base);
+        e->arena.base = nullptr;
+        e->arena.cap = 0;
+        HIPCHK(hipMalloc((void**)&e->arena.base, need_b));
+        HIPCHK(hipMemset(e->arena.base, 0, need_b));  // padded K / V^T regions must never hold NaN bit patterns
+        e->arena.cap = need_b;
+    }
+    e->res_B = B; e->res_N = N; e->res_S = S;
+    return F5_OK;
+}
+
+extern "C" int f5_reserve(f5_engine* e, int32_t B, int32_t N, int32_t S) {
+    if (!e || B <= 0 || N <= 0 || S <= 0) return fail(F5_EINVAL, "f5_reserve: bad arguments");
+    return ensure_arena(e, B, N, S);
+}
+
+template <typename T> static void carve(f5_engine* e, Work<T>& w, int B, int N, int S) {
+    (void)carve_into<T>(e, e->arena, w, B, N, S);
+}
+
+// ---------------------------------------------------------------------------------------------- sub-graphs
+
+template <typename T> static Packed<T>& packed(f5_engine* e);
+template <> Packed<float>& packed<float>(f5_engine* e) { return e->pf; }
+template <> Packed<bf16_t>& packed<bf16_t>(f5_engine* e) { return e->pb; }
+
+// time features -> t_emb [S, D], silu(t_emb), and (DiT) all AdaLN vectors mod [S, modN]
+template <typename T> static int run_time_path(f5_engine* e, Work<T>& w, int S, hipStream_t s) {
+    Packed<T>& P = packed<T>(e);
+    const int D = e->cfg.dim;
+    e->prof.begin(PC_TIME, s);
+    hipLaunchKernelGGL(time_sinus_kernel, dim3((S * 128 + 255) / 256), dim3(256), 0, s, w.tdev, P.time_freqs, w.feat, S, 128);
+    KCHK();
+    HIPCHK(launch_gemm<float>(s, w.feat, 256, P.time0.w, P.time0.ldw, S, D, 256,
+                              EpiStore<float>{w.th, D, P.time0.b, F5_ACT_SILU}));
+    HIPCHK(launch_gemm<float>(s, w.th, D, P.time2.w, P.time2.ldw, S, D, D, EpiStore<float>{w.temb, D, P.time2.b, F5_ACT_NONE}));
+    if (e->cfg.backbone == F5_BACKBONE_DIT) {
+        hipLaunchKernelGGL(act_kernel, dim3(ew_blocks((long)S * D)), dim3(256), 0, s, w.temb, w.st, (long)S * D, F5_ACT_SILU);
+        KCHK();
+        HIPCHK(launch_gemm<float>(s, w.st, D, P.mod.w, P.mod.ldw, S, e->modN, D,
+                                  EpiStore<float>{w.mod, e->modN, P.mod.b, F5_ACT_NONE}));
+    }
+    e->prof.end(s);
+    return F5_OK;
+}
+
+// text ids -> text embedding [B, N, Dt] (dit.py:86-115 + per-sample lengths dit.py:247-258)
+template <typename T>
+static int run_text_embed(f5_engine* e, Work<T>& w, const int64_t* text, int B, int nt, const int* lens_dev, int N,
+                          int drop_text, float* out, hipStream_t s) {
+    Packed<T>& P = packed<T>(e);
+    const f5_config& c = e->cfg;
+    const int Dt = c.text_dim;
+    const bool dit = c.backbone == F5_BACKBONE_DIT;
+    const long rows = (long)B * N;
+    e->prof.begin(PC_TEXT, s);
+    if (c.conv_layers > 0 && dit && N > P.text_pos_rows) return fail(F5_EINVAL, "N=%d exceeds aux.text_pos rows", N);
+    float* cur = c.conv_layers > 0 ? w.tx_a : out;  // block input/output (updated in place); last block writes `out`
+    const int pos_rows = P.text_pos_rows > 0 ? P.text_pos_rows : 1;
+    hipLaunchKernelGGL(text_embed_kernel, dim3(ew_blocks(rows * Dt / 4)), dim3(256), 0, s, (const long long*)text, nt, P.E,
+                       P.text_pos, cur, B, N, Dt, lens_dev, drop_text, c.text_mask_padding && c.conv_layers > 0,
+                       c.conv_layers > 0, dit ? 1 << 30 : pos_rows);
+    KCHK();
+    for (int i = 0; i < c.conv_layers; ++i) {
+        TextBlockW& tb = P.tblocks[i];
+        float* nxt = (i == c.conv_layers - 1) ? out : cur;
+        hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, cur, w.tx_b, tb.dwk, tb.dwb, tb.lnw,
+                           tb.lnb, B, N, Dt, lens_dev, 1e-6f);
+        KCHK();
+        HIPCHK(launch_gemm<float>(s, w.tx_b, Dt, tb.pw1.w, tb.pw1.ldw, (int)rows, 2 * Dt, Dt,
+                                  EpiStore<float>{w.tx_h1, 2 * Dt, tb.pw1.b, F5_ACT_GELU_ERF}));
+        hipLaunchKernelGGL(grn_partial_kernel, dim3((2 * Dt + 255) / 256, GRN_P, B), dim3(256), 0, s, w.tx_h1, w.grn_part,
+                           N, 2 * Dt, lens_dev);
+        KCHK();
+        const int rpb = 16;
+        hipLaunchKernelGGL(grn_apply_kernel, dim3((N + rpb - 1) / rpb, B), dim3(256), (2 * Dt + 8) * sizeof(float), s,
+                           w.tx_h1, w.grn_part, tb.gamma, tb.beta, N, 2 * Dt, lens_dev, rpb);
+        KCHK();
+        // residual add: nxt = cur + pwconv2(h1)
+        HIPCHK(launch_gemm<float>(s, w.tx_h1, 2 * Dt, tb.pw2.w, tb.pw2.ldw, (int)rows, Dt, 2 * Dt,
+                                  EpiGateRes{nxt, cur, Dt, tb.pw2.b, nullptr, 0, N, nullptr}));
+        if (c.text_mask_padding) {
+            hipLaunchKernelGGL(zero_filler_rows_kernel, dim3(ew_blocks(rows * Dt / 4)), dim3(256), 0, s,
+                               (const long long*)text, nt, nxt, B, N, Dt);
+            KCHK();
+        }
+        cur = nxt;
+    }
+    if (lens_dev && c.conv_layers > 0) {
+        hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(ew_blocks(rows * Dt / 4)), dim3(256), 0, s, out, B, N, Dt, lens_dev);
+        KCHK();
+    }
+    e->prof.end(s);
+    return F5_OK;
+}
+
+// One DiT forward over Bp packed rows (dit.py:297-327).  mod_row: AdaLN vectors of this step; mod_stride: distance
+// between batch rows' vectors (0 when every row shares the time step, as in sample()).
+template <typename T>
+static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N,
+                           const float* mod_row, int mod_stride, const int* lens_dev, int drop_cond_first,
+                           const float* text_first, const float* text_second, hipStream_t s) {
+    Packed<T>& P = packed<T>(e);
+    const f5_config& c = e->cfg;
+    const int D = c.dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim, H = c.heads;
+    const int rows = Bp * N;
+    Prof& pr = e->prof;
+    auto gflops = [&](double n, double k) { return 2.0 * rows * n * k; };
+    // input embedding
+    pr.begin(PC_MISC, s);
+    hipLaunchKernelGGL((pack_input_kernel<T>), dim3(ew_blocks((long)rows * e->kin / 4)), dim3(256), 0, s, y, cond,
+                       text_first, text_second, w.acat, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first);
+    KCHK();
+    pr.end(s);
+    pr.begin(PC_GEMM, s, gflops(D, e->kin));
+    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin,
+                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
+    pr.end(s);
+    const double conv_fl = 2.0 * rows * D * (D / 16) * 31;
+    pr.begin(PC_CONV, s, conv_fl);
+    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B));
+    pr.end(s);
+    pr.begin(PC_CONV, s, conv_fl);
+    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B));
+    pr.end(s);
+    const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
+    const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
+    for (int l = 0; l < c.depth; ++l) {
+        BlockW<T>& bw = P.blocks[l];
+        const float* m = mod_row + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
+                           m + D, m, mod_stride, N, 1);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(3 * inner, D));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, 0.125f}));
+        pr.end(s);
+        pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
+        HIPCHK(launch_attention<T>(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(D, inner));
+        HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, lens_dev}));
+        pr.end(s);
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
+                           m + 4 * D, m + 3 * D, mod_stride, N, 1);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(F, D));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(D, F));
+        HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
+                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}));
+        pr.end(s);
+    }
+    const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
+    pr.begin(PC_LN, s);
+    hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f, mf,
+                       mf + D, mod_stride, N, 1);
+    KCHK();
+    pr.end(s);
+    pr.begin(PC_GEMM, s, gflops(mel, D));
+    HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
+                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}));
+    pr.end(s);
+    return F5_OK;
+}
+
+// lens bookkeeping: uploads per-sample lengths (duplicated for the uncond half) through pinned staging
+template <typename T>
+static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, const int32_t* lens_host, int B,
+                        hipStream_t s) {
+    const size_t bytes = (size_t)nT * 4 + (size_t)2 * B * 4 + 64;
+    // the staging buffer may still be read by an earlier async copy on this stream
+    HIPCHK(hipStreamSynchronize(s));
+    CHK(e->stage.ensure(bytes));
+    float* th = reinterpret_cast<float*>(e->stage.host);
+    int* lh = reinterpret_cast<int*>(e->stage.host + (size_t)nT * 4);
+    if (nT > 0) {
+        memcpy(th, t_host, (size_t)nT * 4);
+        HIPCHK(hipMemcpyAsync(w.tdev, th, (size_t)nT * 4, hipMemcpyHostToDevice, s));
+    }
+    if (lens_host) {
+        for (int i = 0; i < B; ++i) lh[i] = lh[B + i] = lens_host[i];
+        HIPCHK(hipMemcpyAsync(w.lens, lh, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+    }
+    return F5_OK;
+}
+
+static int check_ready(f5_engine* e, int B, int N) {
+    if (!e) return fail(F5_EINVAL, "null engine");
+    if (!e->finalized) return fail(F5_ESTATE, "f5_finalize has not been called");
+    if (B <= 0 || N <= 0) return fail(F5_EINVAL, "B and N must be positive");
+    if (N + 1 > e->cfg.max_pos) return fail(F5_EINVAL, "N=%d exceeds the rotary table (%d rows)", N, e->cfg.max_pos);
+    return F5_OK;
+}
+
+template <typename T>
+static int text_embed_impl(f5_engine* e, const int64_t* text, int B, int nt, const int32_t* lens_host, int N,
+                           int drop_text, float* out, hipStream_t s) {
+    CHK(ensure_arena(e, B, N, 1));
+    Work<T> w;
+    carve<T>(e, w, e->res_B, e->res_N, e->res_S);
+    CHK(upload_small<T>(e, w, nullptr, 0, lens_host, B, s));
+    return run_text_embed<T>(e, w, text, B, nt, lens_host ? w.lens : nullptr, N, drop_text, out, s);
+}
+
+extern "C" int f5_text_embed(f5_engine* e, const int64_t* text, int32_t B, int32_t nt, const int32_t* lens_host,
+                             int32_t N, int32_t drop_text, float* out, f5_stream stream) {
+    CHK(check_ready(e, B, N));
+    if (!text || !out || nt <= 0) return fail(F5_EINVAL, "f5_text_embed: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    return e->cfg.precision == F5_PREC_BF16 ? text_embed_impl<bf16_t>(e, text, B, nt, lens_host, N, drop_text, out, s)
+                                            : text_embed_impl<float>(e, text, B, nt, lens_host, N, drop_text, out, s);
+}
+
+template <typename T>
+static int forward_impl(f5_engine* e, const float* x, const float* cond, const int64_t* text, int nt,
+                        const float* time_host, const int32_t* lens_host, int B, int N, int cfg_infer,
+                        int drop_audio_cond, int drop_text, float* out, hipStream_t s) {
+    if (e->cfg.backbone != F5_BACKBONE_DIT) return fail(F5_EINVAL, "f5_dit_forward: UNetT forward goes through f5_sample");
+    const int Bp = cfg_infer ? 2 * B : B;
+    CHK(ensure_arena(e, B, N, Bp));
+    Work<T> w;
+    carve<T>(e, w, e->res_B, e->res_N, e->res_S);
+    std::vector<float> tt(Bp);
+    for (int i = 0; i < Bp; ++i) tt[i] = time_host[i % B];
+    CHK(upload_small<T>(e, w, tt.data(), Bp, lens_host, B, s));
+    const int* lens_dev = lens_host ? w.lens : nullptr;
+    CHK(run_time_path<T>(e, w, Bp, s));
+    if (cfg_infer) {
+        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 0, w.text_c, s));
+        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 1, w.text_u, s));
+        CHK(run_dit_forward<T>(e, w, x, cond, B, Bp, N, w.mod, e->modN, lens_dev, 0, w.text_c, w.text_u, s));
+    } else {
+        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, drop_text, w.text_c, s));
+        CHK(run_dit_forward<T>(e, w, x, cond, B, Bp, N, w.mod, e->modN, lens_dev, drop_audio_cond, w.text_c, w.text_c, s));
+    }
+    HIPCHK(hipMemcpyAsync(out, w.pred, (size_t)Bp * N * e->cfg.mel_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return F5_OK;
+}
+
+extern "C" int f5_dit_forward(f5_engine* e, const float* x, const float* cond, const int64_t* text, int32_t nt,
+                              const float* time_host, const int32_t* lens_host, int32_t B, int32_t N, int32_t cfg_infer,
+                              int32_t drop_audio_cond, int32_t drop_text, float* out, f5_stream stream) {
+    CHK(check_ready(e, B, N));
+    if (!x || !cond || !text || !time_host || !out || nt <= 0) return fail(F5_EINVAL, "f5_dit_forward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    return e->cfg.precision == F5_PREC_BF16
+               ? forward_impl<bf16_t>(e, x, cond, text, nt, time_host, lens_host, B, N, cfg_infer, drop_audio_cond, drop_text, out, s)
+               : forward_impl<float>(e, x, cond, text, nt, time_host, lens_host, B, N, cfg_infer, drop_audio_cond, drop_text, out, s);
+}
+
+template <typename T>
+static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
+                       int nt, const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N,
+                       float* out, float* traj, hipStream_t s) {
+    if (e->cfg.backbone != F5_BACKBONE_DIT) return fail(F5_EINVAL, "UNetT sampling is not built yet");
+    const f5_config& c = e->cfg;
+    const int mel = c.mel_dim;
+    const bool use_cfg = !(cfg_strength < 1e-5f);
+    const int Bp = use_cfg ? 2 * B : B;
+    CHK(ensure_arena(e, B, N, steps));
+    Work<T> w;
+    carve<T>(e, w, e->res_B, e->res_N, e->res_S);
+    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s));
+    const int* lens_dev = lens_host ? w.lens : nullptr;
+    const long half = (long)B * N * mel;
+    // step_cond = where(cond_mask, cond, 0)   (cfm.py:151-153)
+    e->prof.begin(PC_MISC, s);
+    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, cond, (const float*)nullptr,
+                       cond_mask, w.step_cond, (long)B * N, mel);
+    KCHK();
+    e->prof.end(s);
+    CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
+    CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 0, w.text_c, s));
+    if (use_cfg) CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 1, w.text_u, s));
+    float* y = out;  // ODE state lives in the caller's output buffer
+    if (y != y0) HIPCHK(hipMemcpyAsync(y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (traj) HIPCHK(hipMemcpyAsync(traj, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < steps; ++i) {
+        CHK(run_dit_forward<T>(e, w, y, w.step_cond, B, Bp, N, w.mod + (size_t)i * e->modN, 0, lens_dev, 0, w.text_c,
+                               use_cfg ? w.text_u : w.text_c, s));
+        const float dt = t_host[i + 1] - t_host[i];
+        e->prof.begin(PC_MISC, s);
+        hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, y, w.pred, half, dt, cfg_strength,
+                           use_cfg ? 1 : 0, traj ? traj + (size_t)(i + 1) * half : nullptr);
+        KCHK();
+        e->prof.end(s);
+    }
+    // out = where(cond_mask, cond, y)   (cfm.py:221-223)
+    e->prof.begin(PC_MISC, s);
+    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, cond, (const float*)y, cond_mask, out,
+                       (long)B * N, mel);
+    KCHK();
+    e->prof.end(s);
+    return F5_OK;
+}
+
+extern "C" int f5_sample(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
+                         int32_t nt, const float* t_host, int32_t steps, float cfg_strength, const int32_t* lens_host,
+                         int32_t B, int32_t N, float* out, float* traj, f5_stream stream) {
+    CHK(check_ready(e, B, N));
+    if (!cond || !cond_mask || !y0 || !text || !t_host || !out || nt <= 0 || steps <= 0)
+        return fail(F5_EINVAL, "f5_sample: bad arguments");
+    if (B > 1 && !lens_host) return fail(F5_EINVAL, "f5_sample: lens required when B > 1 (cfm.py:155-158)");
+    if (lens_host)
+        for (int i = 0; i < B; ++i)
+            if (lens_host[i] <= 0 || lens_host[i] > N) return fail(F5_EINVAL, "lens[%d]=%d out of (0, N]", i, lens_host[i]);
+    hipStream_t s = (hipStream_t)stream;
+    e->prof.clear();
+    return e->cfg.precision == F5_PREC_BF16
+               ? sample_impl<bf16_t>(e, cond, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s)
+               : sample_impl<float>(e, cond, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s);
+}
+
+extern "C" int f5_profile_enable(f5_engine* e, int32_t on) {
+    if (!e) return fail(F5_EINVAL, "null engine");
+    e->prof.on = on != 0;
+    e->prof.clear();
+    return F5_OK;
+}
+extern "C" int f5_profile_read(f5_engine* e, float* ms, int32_t* launches, double* flops, int32_t ncls) {
+    if (!e || !ms || !launches) return fail(F5_EINVAL, "f5_profile_read: bad arguments");
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < ncls; ++i) {
+        ms[i] = 0.f;
+        launches[i] = 0;
+        if (flops) flops[i] = 0.0;
+    }
+    for (int i = 0; i * 2 + 1 < e->prof.used; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e->prof.ev[2 * i], e->prof.ev[2 * i + 1]));
+        const int cidx = e->prof.cls[i];
+        if (cidx < ncls) {
+            ms[cidx] += t;
+            launches[cidx] += 1;
+            if (flops) flops[cidx] += e->prof.flops[i];
+        }
+    }
+    return F5_OK;
+}

@@ -1,0 +1,69 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the F5-TTS engine.
+// Wave = 64 lanes everywhere; MFMA tiles are 16x16 (bf16: 16x16x32, f32: 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define F5_WAVE 64
+
+// (operand precision ids F5_PREC_F32 / F5_PREC_BF16 live in include/f5_hip.h)
+// activation ids used by GEMM epilogues
+enum { F5_ACT_NONE = 0, F5_ACT_GELU_TANH = 1, F5_ACT_GELU_ERF = 2, F5_ACT_SILU = 3, F5_ACT_MISH = 4 };
+
+namespace f5 {
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // torch: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float mish(float x) {
+    // x * tanh(softplus(x)); torch softplus threshold 20
+    float sp = x > 20.0f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case F5_ACT_GELU_TANH: return gelu_tanh(v);
+        case F5_ACT_GELU_ERF: return gelu_erf(v);
+        case F5_ACT_SILU: return silu(v);
+        case F5_ACT_MISH: return mish(v);
+        default: return v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace f5

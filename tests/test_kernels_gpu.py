@@ -1,0 +1,126 @@
+"""GPU: every hand-written kernel against a torch fp32 restatement of the same op (through the C ABI's f5k_* entry
+points).  f32 mode must agree to fp32 rounding; bf16 mode to bf16 operand rounding (tolerances written per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, k_attention, k_convpos, k_gemm, k_layernorm_mod  # noqa: E402
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+GEMM_SHAPES = [(2048, 1024, 1024), (2048, 3072, 1024), (2048, 1024, 2048), (300, 100, 1024), (77, 64, 712),
+               (16, 6144, 1024), (1, 4, 8), (130, 260, 40), (513, 1028, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 1.5e-2)])
+def test_gemm_bias_matches_torch(M, N, K, prec, tol):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    ref = F.linear(A.double(), W.double(), b.double()).float()
+    out = k_gemm(prec, A, W, b)
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < tol
+
+
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gemm_every_tile_shape_and_identity(tile, prec):
+    """A = I with an ASYMMETRIC W catches a transposed accumulator map (guide section 3)."""
+    M = N = K = 256
+    A = torch.eye(M).to(DEV)
+    W = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).to(DEV) / 16  # exact in bf16
+    out = k_gemm(prec, A, W, None, tile=tile)
+    assert torch.equal(out, W.t().contiguous())
+
+
+@pytest.mark.parametrize("act,fn", [(1, lambda x: F.gelu(x, approximate="tanh")), (2, F.gelu), (3, F.silu), (4, F.mish)])
+def test_gemm_activation_epilogues(act, fn):
+    g = torch.Generator().manual_seed(act)
+    A = torch.randn(200, 96, generator=g).to(DEV)
+    W = (torch.randn(128, 96, generator=g) * 0.2).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    ref = fn(F.linear(A, W, b))
+    out = k_gemm("f32", A, W, b, act=act)
+    assert (out - ref).abs().max() < 2e-5
+
+
+def sdpa_ref(q, k, v, lens=None):
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) / 8.0
+    if lens is not None:
+        N = q.shape[2]
+        m = torch.arange(N, device=q.device)[None, :] < torch.tensor(lens, device=q.device)[:, None]
+        s = s.masked_fill(~m[:, None, None, :], float("-inf"))
+    o = torch.matmul(torch.softmax(s, dim=-1), v.double())
+    return o.transpose(1, 2).reshape(q.shape[0], q.shape[2], -1).float()
+
+
+@pytest.mark.parametrize("Bp,H,N", [(2, 16, 1024), (1, 4, 64), (2, 4, 48), (3, 2, 200), (1, 2, 129), (2, 3, 777)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
+def test_attention_matches_sdpa(Bp, H, N, prec, tol):
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(Bp, H, N, 64, generator=g).to(DEV) for _ in range(3))
+    out = k_attention(prec, q, k, v)
+    ref = sdpa_ref(q, k, v)
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
+def test_attention_key_padding_mask_and_peaked_softmax(prec, tol):
+    """attn_mask_enabled path (modules.py:501-506) + a forced running-max jump (one key dominates late)."""
+    g = torch.Generator().manual_seed(3)
+    Bp, H, N = 3, 2, 300
+    q, k, v = (torch.randn(Bp, H, N, 64, generator=g).to(DEV) for _ in range(3))
+    k[:, :, 250] = q[:, :, 7] * 3.0  # key 250 spikes against query 7: max jumps in the last tile
+    lens = [300, 131, 257]
+    out = k_attention(prec, q, k, v, lens)
+    ref = sdpa_ref(q, k, v, lens)
+    assert (out - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("D,N,Bp", [(256, 48, 2), (1024, 300, 2), (512, 129, 1), (1024, 1024, 2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
+def test_convpos_matches_conv1d_mish(D, N, Bp, prec, tol):
+    g = torch.Generator().manual_seed(D + N)
+    x = torch.randn(Bp, N, D, generator=g).to(DEV)
+    w = (torch.randn(D, D // 16, 31, generator=g) * (1.0 / (31 * D / 16) ** 0.5)).to(DEV)
+    b = torch.randn(D, generator=g).to(DEV)
+    res = torch.randn(Bp, N, D, generator=g).to(DEV)
+    ref = F.mish(F.conv1d(x.permute(0, 2, 1), w, b, padding=15, groups=16)).permute(0, 2, 1) + res
+    out = k_convpos(prec, x, w, b, res)
+    assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+
+
+def test_convpos_masked_rows():
+    g = torch.Generator().manual_seed(9)
+    Bp, N, D = 2, 150, 256
+    x = torch.randn(Bp, N, D, generator=g).to(DEV)
+    w = (torch.randn(D, 16, 31, generator=g) * 0.05).to(DEV)
+    b = torch.randn(D, generator=g).to(DEV)
+    lens = [150, 97]
+    m = (torch.arange(N, device=DEV)[None] < torch.tensor(lens, device=DEV)[:, None])[:, None]  # [B,1,N]
+    h = x.permute(0, 2, 1).masked_fill(~m, 0.0)
+    h = F.conv1d(h, w, b, padding=15, groups=16).masked_fill(~m, 0.0)
+    ref = F.mish(h).permute(0, 2, 1)
+    out = k_convpos("f32", x, w, b, None, lens)
+    assert (out - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("D", [64, 256, 512, 1024])
+def test_layernorm_modulate(D):
+    g = torch.Generator().manual_seed(D)
+    R, rpb = 96, 32
+    x = (torch.randn(R, D, generator=g) * 3 + 1).to(DEV)
+    sc = torch.randn(R // rpb, D, generator=g).to(DEV)
+    sh = torch.randn(R // rpb, D, generator=g).to(DEV)
+    ref = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc.repeat_interleave(rpb, 0)) + sh.repeat_interleave(rpb, 0)
+    out = k_layernorm_mod(x, sc, sh, rpb)
+    assert (out - ref).abs().max() < 2e-5
