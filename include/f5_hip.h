@@ -119,7 +119,7 @@ typedef struct f5_vocos_config {
 int f5_vocos_create(const f5_vocos_config* cfg, f5_vocos** out);
 int f5_vocos_destroy(f5_vocos* v);
 /* names: backbone.embed.weight, backbone.convnext.N.{dwconv,norm,pwconv1,pwconv2}.{weight,bias}, ...gamma, head.out.*;
- * aux.hann [n_fft], aux.idft_basis [n_fft, 2*(n_fft/2+1) rounded up to a multiple of 4] (window folded in). */
+ * aux.hann [n_fft], aux.idft_basis [n_fft, 2*(n_fft/2+1) rounded up to a multiple of 32] (window folded in). */
 int f5_vocos_load_weight(f5_vocos* v, const char* name, const void* dev_f32, const int64_t* shape, int32_t ndim,
                          f5_stream stream);
 int f5_vocos_finalize(f5_vocos* v, f5_stream stream);

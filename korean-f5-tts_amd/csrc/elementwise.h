@@ -347,17 +347,20 @@ __global__ void cast_pad_kernel(const float* __restrict__ in, int ld_in, int row
 }
 
 // ------------------------------------------------------------------------------------------------ Vocos
-// A[b*T + t][k*C + ci] = mel[b][ci][t + k - 3]  (Conv1d(C, dim, k=7, pad=3) as a GEMM)
-static __global__ void im2col7_kernel(const float* __restrict__ mel, float* __restrict__ A, int B, int C, int T) {
-    const long total = (long)B * T * 7 * C;
+// A[b*T + t][k*C + ci] = mel[b][ci][t + k - 3]  (Conv1d(C, dim, k=7, pad=3) as a GEMM); columns >= 7*C zero (K padding)
+static __global__ void im2col7_kernel(const float* __restrict__ mel, float* __restrict__ A, int B, int C, int T, int ld) {
+    const long total = (long)B * T * ld;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % C);
-        long r = i / C;
-        const int k = (int)(r % 7);
-        r /= 7;
+        const int col = (int)(i % ld);
+        const long r = i / ld;
         const int t = (int)(r % T), b = (int)(r / T);
-        const int tt = t + k - 3;
-        A[i] = (tt >= 0 && tt < T) ? mel[((size_t)b * C + ci) * T + tt] : 0.f;
+        float v = 0.f;
+        if (col < 7 * C) {
+            const int k = col / C, ci = col - k * C;
+            const int tt = t + k - 3;
+            if (tt >= 0 && tt < T) v = mel[((size_t)b * C + ci) * T + tt];
+        }
+        A[i] = v;
     }
 }
 // ISTFT head (export_vocoder_to_onnx.py:51-59): h[r, 0:F] = log-magnitude, h[r, F:2F] = phase;

@@ -28,7 +28,7 @@
 #include "attn.h"
 #include "convpos.h"
 #include "elementwise.h"
-#include "gemm.h"
+#include "gemm_dispatch.h"
 
 using namespace f5;
 
@@ -213,7 +213,7 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     e->cfg = *c;
     e->inner = c->heads * 64;
     e->kin = 2 * c->mel_dim + c->text_dim;
-    e->kin_pad = round_up(e->kin, 8);
+    e->kin_pad = round_up(e->kin, 64);  // whole 128-byte K-tiles for the LDS-DMA GEMM (pad columns stay zero)
     e->modN = (6 * c->depth + 2) * c->dim;
     *out = e;
     return F5_OK;
@@ -256,7 +256,7 @@ static int pack_linear(f5_engine* e, hipStream_t s, const std::string& wname, co
     const int Np = n_pad ? n_pad : N;
     L->N = Np;
     L->K = K;
-    L->ldw = round_up(K, 8);
+    L->ldw = round_up(K, 64);
     CHK(dev_alloc(e, &L->w, (size_t)Np * L->ldw));
     hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)Np * L->ldw)), dim3(256), 0, s, w->p, K, N, K, L->w,
                        L->ldw, Np);
@@ -277,7 +277,7 @@ static int pack_concat(f5_engine* e, hipStream_t s, const std::vector<std::strin
     const int n = (int)pfx.size();
     L->N = n * Ni;
     L->K = K;
-    L->ldw = round_up(K, 8);
+    L->ldw = round_up(K, 64);
     CHK(dev_alloc(e, &L->w, (size_t)L->N * L->ldw));
     L->b = nullptr;
     if (bias) CHK(dev_alloc(e, &L->b, (size_t)L->N));
@@ -614,7 +614,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(D, e->kin));
-    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin,
+    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
                           EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
     pr.end(s);
     const double conv_fl = 2.0 * rows * D * (D / 16) * 31;

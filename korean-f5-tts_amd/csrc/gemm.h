@@ -256,8 +256,8 @@ inline hipError_t launch_gemm_tile(hipStream_t s, const T* A, int lda, const T* 
 
 // A: [M, K] (lda elements), W: [N, K] (ldw elements); K, lda, ldw multiples of 16/sizeof(T); N multiple of 4.
 template <typename T, typename Epi>
-inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                              const Epi& epi, int force_bm = 0, int force_bn = 0) {
+inline hipError_t launch_gemm_v1(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                 const Epi& epi, int force_bm = 0, int force_bn = 0) {
     if (M <= 0 || N <= 0) return hipSuccess;
     GemmTile t = pick_tile(M, N);
     if (force_bm) t = {force_bm, force_bn};

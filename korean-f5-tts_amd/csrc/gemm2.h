@@ -1,0 +1,159 @@
+// Pipelined MFMA "TN" GEMM (v2): same contract and epilogues as gemm.h, different data movement.
+//
+//   * operands go HBM/L2 -> LDS directly with global_load_lds (16 B per lane, 1 KiB per wave-instruction, no VGPR
+//     staging, no ds_write); the LDS image of a tile is [rows][128 B] with NO padding (LDS-DMA writes lane-linear),
+//     bank conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address and to the fragment reads
+//     (16-byte chunk c of row r lives in slot c ^ (r & 7));
+//   * NS-stage ring (NS-1 K-tiles issued ahead), ONE raw s_barrier per K-tile, counted `s_waitcnt vmcnt(N)` that only
+//     retires the tile about to be consumed -- the loads of the next NS-2 tiles stay in flight across the barrier;
+//   * tail handling without branches: past the last K-tile the loaders re-issue the last tile into stages nobody reads
+//     again (keeps the vmcnt arithmetic constant); rows beyond M / N are clamped (their results are never stored).
+// Requirements: K % (128 / sizeof(T)) == 0 (the engine pads K), lda/ldw multiples of 16 bytes.
+#pragma once
+#include "gemm.h"
+
+namespace f5 {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
+                                                                   const T* __restrict__ W, int ldw, int M, int N, int K,
+                                                                   Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = WM * WN;
+    constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
+    constexpr int MI = TM / 16, NJ = TN / 16;
+    constexpr int STAGE = (BM + BN) * GEMM_ROW_BYTES;   // bytes per ring stage
+    constexpr int RG_A = BM / 8, RG_W = BN / 8;         // 8-row groups (= 1 KiB glds pieces)
+    constexpr int LA = RG_A / NW, LW = RG_W / NW;       // pieces per wave per K-tile
+    static_assert(RG_A % NW == 0 && RG_W % NW == 0, "tile rows must split evenly over the waves");
+    constexpr int L = LA + LW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nkt = K / KT;
+    const bool transposed = epi.tile_transposed(n0);
+
+    // per-lane source pointers for this wave's pieces (row inside the 8-row group = lane >> 3, swizzled chunk)
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const T* asrc[LA];
+    const T* wsrc[LW];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int row = min(m0 + (wave + i * NW) * 8 + lr, M - 1);
+        asrc[i] = A + (size_t)row * lda + lc * EPC;
+    }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+        const int row = min(n0 + (wave + i * NW) * 8 + lr, N - 1);
+        wsrc[i] = W + (size_t)row * ldw + lc * EPC;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* base = smem + stage * STAGE;
+        const int koff = min(kt, nkt - 1) * KT;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) glds16(asrc[i] + koff, base + (wave + i * NW) * 1024);
+#pragma unroll
+        for (int i = 0; i < LW; ++i) glds16(wsrc[i] + koff, base + BM * GEMM_ROW_BYTES + (wave + i * NW) * 1024);
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing: row R = base + l15 (base multiple of 16), chunk c = kk*4 + g  ->  R*128 + ((c ^ (R&7)) * 16)
+    const int l15 = lane & 15, g = lane >> 4;
+    const int sw = l15 & 7;
+    const int a_row_off = (wr * TM + l15) * GEMM_ROW_BYTES;
+    const int w_row_off = BM * GEMM_ROW_BYTES + (wc * TN + l15) * GEMM_ROW_BYTES;
+    const int c0 = ((0 + g) ^ sw) * 16, c1 = ((4 + g) ^ sw) * 16;
+
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t, t);
+
+    int stage = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        wait_vmcnt<(NS - 2) * L>();       // this wave's pieces of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
+        int pf = stage + NS - 1;
+        if (pf >= NS) pf -= NS;
+        issue(kt + NS - 1, pf);
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int co = kk ? c1 : c0;
+            u32x4 af[MI], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const u32x4*>(sb + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const u32x4*>(sb + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
+            if (!transposed) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(wf[j], af[i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(af[i], wf[j], acc[i][j]);
+            }
+        }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();  // drain the dummy tail loads before the block's LDS can be reallocated
+
+    const int mw = m0 + wr * TM, nw = n0 + wc * TN;
+    if (!transposed) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nw + j * 16 + g * 4;
+                if (m < M && n < N) epi.row4(m, n, acc[i][j], M, N);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 16 + g * 4;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nw + j * 16 + l15;
+                if (m < M && n < N) epi.col4(m, n, acc[i][j], M, N);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi>
+inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                   const Epi& epi) {
+    constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
+                       ldw, M, N, K, epi);
+    return hipGetLastError();
+}
+
+}  // namespace f5

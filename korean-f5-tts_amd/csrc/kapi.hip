@@ -6,7 +6,7 @@
 #include "attn.h"
 #include "convpos.h"
 #include "elementwise.h"
-#include "gemm.h"
+#include "gemm_dispatch.h"
 #include "internal.h"
 
 using namespace f5;
@@ -15,14 +15,15 @@ using namespace f5;
 template <typename T>
 static int gemm_impl(const float* A, const float* W, const float* bias, int act, float* out, int M, int N, int K, int tm,
                      int tn, hipStream_t s) {
-    const int Kp = round_up(K, 8);
+    const int Kp = tm > 0 ? round_up(K, 8) : round_up(K, 128 / (int)sizeof(T));  // tm > 0 forces the v1 kernel
     Scratch<T> a, w;
     HIPCHK(a.alloc((size_t)M * Kp));
     HIPCHK(w.alloc((size_t)N * Kp));
     hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)M * Kp)), dim3(256), 0, s, A, K, M, K, a.p, Kp, M);
     hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)N * Kp)), dim3(256), 0, s, W, K, N, K, w.p, Kp, N);
     KCHK();
-    HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm, tn));
+    if (tm > 0) HIPCHK(launch_gemm_v1<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm, tn));
+    else HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm < 0 ? -tm : -1));
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
 }
@@ -30,7 +31,8 @@ static int gemm_impl(const float* A, const float* W, const float* bias, int act,
 extern "C" int f5k_gemm(int32_t prec, const float* A, const float* W, const float* bias, int32_t act, float* out, int32_t M,
                         int32_t N, int32_t K, int32_t tm, int32_t tn, f5_stream stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % 4)) return fail(F5_EINVAL, "f5k_gemm: bad arguments (N %% 4 == 0)");
-    if (tm && !((tm == 128 && (tn == 128 || tn == 64)) || (tm == 64 && tn == 64))) return fail(F5_EINVAL, "f5k_gemm: bad tile");
+    if (tm > 0 && !((tm == 128 && (tn == 128 || tn == 64)) || (tm == 64 && tn == 64))) return fail(F5_EINVAL, "f5k_gemm: bad tile");
+    if (tm < 0 && tm != -2 && tm != -8 && tm != -9) return fail(F5_EINVAL, "f5k_gemm: bad v2 config id");
     hipStream_t s = (hipStream_t)stream;
     return prec == F5_PREC_BF16 ? gemm_impl<bf16_t>(A, W, bias, act, out, M, N, K, tm, tn, s)
                                 : gemm_impl<float>(A, W, bias, act, out, M, N, K, tm, tn, s);
@@ -38,7 +40,7 @@ extern "C" int f5k_gemm(int32_t prec, const float* A, const float* W, const floa
 
 template <typename T>
 static int gemm_time_impl(int M, int N, int K, int tm, int tn, int iters, float* avg_us, hipStream_t s) {
-    const int Kp = round_up(K, 8);
+    const int Kp = tm > 0 ? round_up(K, 8) : round_up(K, 128 / (int)sizeof(T));
     Scratch<T> a, w, o;
     HIPCHK(a.alloc((size_t)M * Kp));
     HIPCHK(w.alloc((size_t)N * Kp));
@@ -60,9 +62,13 @@ static int gemm_time_impl(int M, int N, int K, int tm, int tn, int iters, float*
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm, tn));
+    auto go = [&]() -> hipError_t {
+        if (tm > 0) return launch_gemm_v1<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm, tn);
+        return launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm < 0 ? -tm : -1);
+    };
+    for (int i = 0; i < 3; ++i) HIPCHK(go());
     HIPCHK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm, tn));
+    for (int i = 0; i < iters; ++i) HIPCHK(go());
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -170,4 +176,64 @@ extern "C" int f5k_layernorm_mod(const float* x, const float* scale, const float
     KCHK();
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
+}
+
+// ------------------------------------------------------------------------------------ v2 (glds ring) GEMM
+#include "gemm2.h"
+
+template <typename T, typename Epi>
+static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                 const Epi& epi) {
+    switch (cfg) {
+        case 0: return launch_gemm2_cfg<T, 128, 128, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 1: return launch_gemm2_cfg<T, 128, 128, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 2: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 3: return launch_gemm2_cfg<T, 128, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 4: return launch_gemm2_cfg<T, 128, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 5: return launch_gemm2_cfg<T, 64, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 6: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 7: return launch_gemm2_cfg<T, 128, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 8: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 9: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+static int gemm2_impl(const float* A, const float* W, const float* bias, int act, float* out, int M, int N, int K, int cfg,
+                      int iters, float* avg_us, hipStream_t s) {
+    const int Kp = round_up(K, 128 / (int)sizeof(T));
+    Scratch<T> a, w;
+    HIPCHK(a.alloc((size_t)M * Kp));
+    HIPCHK(w.alloc((size_t)N * Kp));
+    hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)M * Kp)), dim3(256), 0, s, A, K, M, K, a.p, Kp, M);
+    hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)N * Kp)), dim3(256), 0, s, W, K, N, K, w.p, Kp, N);
+    KCHK();
+    HIPCHK(gemm2_dispatch<T>(cfg, s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}));
+    if (iters > 0 && avg_us) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i)
+            HIPCHK(gemm2_dispatch<T>(cfg, s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}));
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = ms * 1000.f / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return F5_OK;
+}
+
+// experimental entry (not in the public header): v2 GEMM with config id; optional timing over `iters` launches
+extern "C" int f5x_gemm2(int32_t prec, const float* A, const float* W, const float* bias, int32_t act, float* out, int32_t M,
+                         int32_t N, int32_t K, int32_t cfg, int32_t iters, float* avg_us, f5_stream stream) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % 4)) return fail(F5_EINVAL, "f5x_gemm2: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    return prec == F5_PREC_BF16 ? gemm2_impl<bf16_t>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s)
+                                : gemm2_impl<float>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s);
 }

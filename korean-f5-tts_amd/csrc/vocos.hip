@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "elementwise.h"
-#include "gemm.h"
+#include "gemm_dispatch.h"
 #include "internal.h"
 
 using namespace f5;
@@ -51,8 +51,8 @@ extern "C" int f5_vocos_create(const f5_vocos_config* c, f5_vocos** out) {
     f5_vocos* v = new f5_vocos();
     v->cfg = *c;
     v->F = c->n_fft / 2 + 1;
-    v->K2 = round_up(2 * v->F, 4);
-    v->kemb = 7 * c->input_channels;
+    v->K2 = round_up(2 * v->F, 32);            // whole 128-byte K-tiles (f32) for the LDS-DMA GEMM
+    v->kemb = round_up(7 * c->input_channels, 32);
     v->head_n = round_up(c->n_fft + 2, 4);
     *out = v;
     return F5_OK;
@@ -114,12 +114,19 @@ extern "C" int f5_vocos_finalize(f5_vocos* v, f5_stream stream) {
     const VT* t = nullptr;
     CHK(vneed(v, "backbone.embed.weight", {D, C, 7}, &t));
     void* p = nullptr;
-    HIPCHK(hipMalloc(&p, (size_t)D * v->kemb * 4));
-    v->owned.push_back(p);
-    v->emb_w = (float*)p;
-    hipLaunchKernelGGL((permute_last2_kernel<float>), dim3(ew_blocks((long)D * v->kemb)), dim3(256), 0, s, t->p, v->emb_w,
-                       (long)D, C, 7);
-    KCHK();
+    {
+        Scratch<float> tmp;  // [D, 7*C] tap-major, then zero-padded to kemb columns
+        HIPCHK(tmp.alloc((size_t)D * 7 * C));
+        hipLaunchKernelGGL((permute_last2_kernel<float>), dim3(ew_blocks((long)D * 7 * C)), dim3(256), 0, s, t->p, tmp.p,
+                           (long)D, C, 7);
+        HIPCHK(hipMalloc(&p, (size_t)D * v->kemb * 4));
+        v->owned.push_back(p);
+        v->emb_w = (float*)p;
+        hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(ew_blocks((long)D * v->kemb)), dim3(256), 0, s, tmp.p, 7 * C, D,
+                           7 * C, v->emb_w, v->kemb, D);
+        KCHK();
+        HIPCHK(hipStreamSynchronize(s));
+    }
     CHK(vcopy(v, s, "backbone.embed.bias", {D}, &v->emb_b));
     CHK(vcopy(v, s, "backbone.norm.weight", {D}, &v->n0w));
     CHK(vcopy(v, s, "backbone.norm.bias", {D}, &v->n0b));
@@ -202,7 +209,7 @@ extern "C" int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t
     }
     (void)plan(v->arena, &col, &x, &t1, &h, &hd, &S, &fr);
 
-    hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks(R * v->kemb)), dim3(256), 0, s, mel, col, B, C, T);
+    hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks(R * v->kemb)), dim3(256), 0, s, mel, col, B, C, T, v->kemb);
     KCHK();
     HIPCHK(launch_gemm<float>(s, col, v->kemb, v->emb_w, v->kemb, (int)R, D, v->kemb, EpiStore<float>{t1, D, v->emb_b, F5_ACT_NONE}));
     hipLaunchKernelGGL((layernorm_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, s, t1, D, x, D, (int)R, D, 1e-6f, v->n0w,

@@ -18,7 +18,7 @@ def idft_basis(n_fft: int) -> tuple[torch.Tensor, torch.Tensor]:
     """(hann window [n_fft], Basis [n_fft, K2]) such that frames = [Re S | Im S | 0-pad] @ Basis^T equals
     irfft(S, n_fft) * hann  (what torch.istft computes per frame).  float64 on the host, rounded once to f32."""
     Fb = n_fft // 2 + 1
-    K2 = (2 * Fb + 3) // 4 * 4
+    K2 = (2 * Fb + 31) // 32 * 32  # whole 128-byte K-tiles of the f32 LDS-DMA GEMM
     j = torch.arange(n_fft, dtype=torch.float64)[:, None]
     f = torch.arange(Fb, dtype=torch.float64)[None, :]
     ang = 2 * torch.pi * f * j / n_fft

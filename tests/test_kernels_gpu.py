@@ -30,7 +30,7 @@ def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     assert rel_err(out, ref) < tol
 
 
-@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64), (-2, 0), (-8, 0), (-9, 0)])  # v1 tiles, v2 config ids
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_gemm_every_tile_shape_and_identity(tile, prec):
     """A = I with an ASYMMETRIC W catches a transposed accumulator map (guide section 3)."""
