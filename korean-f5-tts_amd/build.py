@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libf5hip.so")
 OBJDIR = os.path.join(ROOT, "build", "f5hip")
 SOURCES = ["engine.hip", "vocos.hip", "kapi.hip"]
-HEADERS = ["f5_common.h", "gemm.h", "attn.h", "convpos.h", "elementwise.h", "internal.h", "../../include/f5_hip.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/f5_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable"]
 

@@ -1,0 +1,271 @@
+// Flash attention v2 for dim_head = 64 (same contract as attn.h): 8 waves per 128-query block, K/V^T tiles streamed by
+// LDS-DMA through a 3-stage ring, key-split wave pairs.
+//
+//   wave = (qg, kh): query group qg (32 query rows, as in attn.h) x key half kh of every 64-key tile.  Each wave runs
+//   its OWN online softmax over its key subset (running max m, partial sum l, O^T accumulator); the two halves of a
+//   pair are merged once at the end through LDS (flash-decoding style):  m = max(m0, m1), O = O0 e^(m0-m) + O1 e^(m1-m).
+//   Two waves per SIMD: one's softmax VALU work overlaps the other's MFMAs (dh = 64 attention is VALU-heavy:
+//   ~0.34 VALU cycles per score vs 0.25 MFMA cycles).
+//   The accumulator rescale by e^(m_old - m_new) is skipped while no lane of the wave sees its running max grow
+//   (exact: the factor is 1), which removes most of the O-wide multiplies after the first few tiles.
+//   Key order inside a 32-key half: MFMA row 4a + b of S^T sub-tile ks is key 8a + 4ks + b, so that lane group g ends
+//   up owning the 8 CONSECUTIVE keys 8g..8g+7 -- its P^T fragment pairs with ONE 16-byte V^T fragment read.
+//   LDS image: K tile [64 keys][128 B], 16-byte chunk c of row r in slot c ^ kswz(r); V^T tile [64 dh][128 B], slot
+//   c ^ (r & 7); both make every ds_read_b128 fragment read conflict-free.  The swizzle is applied to the per-lane
+//   SOURCE address of the LDS-DMA (the LDS side of a global_load_lds is lane-linear).
+// bf16 operands only (the exact-f32 precision keeps attn.h's kernel).
+#pragma once
+#include "attn.h"
+#include "gemm2.h"
+
+namespace f5 {
+
+// One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
+// key-padding mask costs nothing on interior tiles.
+template <int STAGE_IDX, bool EDGE>
+__device__ __forceinline__ void attn2_tile(const char* __restrict__ smem, int k_off, int kc0, int kc1, int v_off, int vc,
+                                           const u32x4 (&qf)[2][2], f32x4 (&o)[4][2], float (&mrun)[2], float (&lrun)[2],
+                                           int key_base, int kv_len) {
+    constexpr int TILE = 64 * 128;
+    constexpr float L2E = 1.4426950408889634f;
+    const char* sb = smem + STAGE_IDX * (2 * TILE);
+    // ---- S^T (this wave's 32 keys x 32 queries); MFMA row i = 4a + b of sub-tile ks holds key 8a + 4ks + b
+    f32x4 s[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(sb + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf, qf[qs][f], s[ks][qs]);
+        }
+    }
+    // ---- online softmax over this wave's keys (lane group g owns keys key_base + 4 ks + r)
+    float alpha[2];
+    bool grew = false;
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        if (EDGE) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key_base + ks * 4 + r >= kv_len) s[ks][qs][r] = -1e30f;
+        }
+        float mloc = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
+                           fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(mrun[qs], mloc);
+        grew = grew || (mnew > mrun[qs]);
+        alpha[qs] = __builtin_amdgcn_exp2f((mrun[qs] - mnew) * L2E);
+        mrun[qs] = mnew;
+        const float mb = mnew * L2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[ks][qs][r] * L2E - mb);
+                if (EDGE && key_base + ks * 4 + r >= kv_len) p = 0.f;
+                s[ks][qs][r] = p;
+                psum += p;
+            }
+        lrun[qs] = lrun[qs] * alpha[qs] + psum;
+    }
+    if (__any(grew)) {  // wave-uniform: skip the O-wide rescale when every factor is exactly 1
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt][qs][0] *= alpha[qs]; o[dt][qs][1] *= alpha[qs]; o[dt][qs][2] *= alpha[qs]; o[dt][qs][3] *= alpha[qs];
+            }
+    }
+    // ---- O^T += V^T P^T: one 32-key MFMA step; lane group g supplies keys 8g .. 8g+7 of this wave's half on both sides
+    u32x4 pf2[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        bf16x8 pv = {(bf16_t)s[0][qs][0], (bf16_t)s[0][qs][1], (bf16_t)s[0][qs][2], (bf16_t)s[0][qs][3],
+                     (bf16_t)s[1][qs][0], (bf16_t)s[1][qs][1], (bf16_t)s[1][qs][2], (bf16_t)s[1][qs][3]};
+        pf2[qs] = __builtin_bit_cast(u32x4, pv);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const u32x4 vf = *reinterpret_cast<const u32x4*>(sb + v_off + dt * 16 * 128 + vc);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<bf16_t>::run(vf, pf2[qs], o[dt][qs]);
+    }
+}
+
+// K-tile swizzle: 16-byte chunk c of key row r lives in slot c ^ kswz(r).  The S^T fragment of sub-tile ks reads the 16
+// rows {8a + 4ks + b}; kswz makes those land on 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int kswz(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }
+
+static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int H,
+                                                               int N, int Npad, const int* __restrict__ kv_lens,
+                                                               int nbatch_lens) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 3;
+    constexpr int TILE = 64 * 128;      // bytes of one K or V^T tile
+    constexpr int STAGE = 2 * TILE;
+    constexpr int L = 2;                // LDS-DMA pieces per wave per tile (16 pieces of 1 KiB over 8 waves)
+    constexpr float L2E = 1.4426950408889634f;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave >> 1, kh = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    // grid: x = (batch row, head), y = query block -- consecutive workgroup ids (dealt round-robin over the 8 XCDs)
+    // are different heads, so the 8 query blocks that share one head's K/V meet in ONE XCD's L2
+    const int bhid = blockIdx.x;
+    const int b = bhid / H, h = bhid - b * H;
+    const size_t bh = (size_t)bhid;
+    const int q0 = blockIdx.y * 128 + qg * 32;
+    int kv_len = N;
+    if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
+    const int nkt = (kv_len + 63) / 64;
+
+    // Q fragments (B operand of S^T = K Q^T): row q, 16-byte chunk f*4 + g
+    u32x4 qf[2][2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int q = min(q0 + qs * 16 + l15, N - 1);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+            qf[qs][f] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Q + (bh * N + q) * 64) + f * 64 + g * 16);
+    }
+
+    // LDS-DMA sources: wave w stages piece w of the K tile (keys 8w..8w+7) and piece w of the V^T tile (dh rows 8w..8w+7)
+    const int lr = lane >> 3, ls = lane & 7;
+    const int krow = wave * 8 + lr;                       // key row inside the tile
+    const int kchunk = ls ^ kswz(krow);
+    const int vrow = wave * 8 + lr;                       // dh row
+    const int vchunk = ls ^ (vrow & 7);
+    const bf16_t* ksrc = K + bh * (size_t)N * 64 + kchunk * 8;
+    const bf16_t* vsrc = Vt + (bh * 64 + vrow) * (size_t)Npad + vchunk * 8;
+    auto issue = [&](int kt, int stage) {
+        const int t = min(kt, nkt - 1);
+        char* base = smem + stage * STAGE;
+        const int key = min(t * 64 + krow, N - 1);        // rows past N are clamped; their scores are masked
+        glds16(ksrc + (size_t)key * 64, base + wave * 1024);
+        glds16(vsrc + t * 64, base + TILE + wave * 1024);
+    };
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+
+    // fragment read offsets (stage base and sub-tile strides are compile-time immediates in attn2_tile)
+    const int ka = l15 >> 2, kb = l15 & 3;
+    const int krd = kh * 32 + 8 * ka + kb;                // + 4 ks
+    const int ksw = kswz(krd);                            // independent of ks (bit 2 of the row is not used)
+    const int k_off = krd * 128;
+    const int kc0 = ((0 + g) ^ ksw) * 16, kc1 = ((4 + g) ^ ksw) * 16;
+    const int v_off = TILE + l15 * 128;
+    const int vc = ((4 * kh + g) ^ (l15 & 7)) * 16;       // keys 32 kh + 8 g .. + 7 of dh row dt*16 + l15
+    const int key_lane = kh * 32 + 8 * g;                 // first key (inside the tile) owned by this lane group
+
+    issue(0, 0);
+    issue(1, 1);
+    const int nfull = kv_len / 64;                        // tiles without masked keys
+    int kt = 0;
+#define F5_ATTN_STEP(SI, EDGE_)                                                                                        \
+    {                                                                                                                  \
+        wait_vmcnt<(NS - 2) * L>();                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        issue(kt + NS - 1, (SI + NS - 1) % NS);                                                                        \
+        attn2_tile<SI, EDGE_>(smem, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
+        ++kt;                                                                                                          \
+    }
+    while (kt + 3 <= nfull) {
+        F5_ATTN_STEP(0, false)
+        F5_ATTN_STEP(1, false)
+        F5_ATTN_STEP(2, false)
+    }
+    // remainder: up to 2 full tiles + at most one edge tile, continuing the stage rotation (kt % 3 == 0 here)
+    if (kt < nkt) { if (kt < nfull) F5_ATTN_STEP(0, false) else F5_ATTN_STEP(0, true) }
+    if (kt < nkt) { if (kt < nfull) F5_ATTN_STEP(1, false) else F5_ATTN_STEP(1, true) }
+    if (kt < nkt) { F5_ATTN_STEP(2, true) }
+#undef F5_ATTN_STEP
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring: reuse it for the pair merge
+
+    // ---- merge the two key halves of each query group (kh = 1 publishes, kh = 0 combines and stores)
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        lrun[qs] = l;
+    }
+    float* mb = reinterpret_cast<float*>(smem) + (size_t)qg * (36 * 64);   // [36][64 lanes] per pair
+    if (kh == 1) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mb[((dt * 2 + qs) * 4 + r) * 64 + lane] = o[dt][qs][r];
+        mb[32 * 64 + lane] = mrun[0];
+        mb[33 * 64 + lane] = mrun[1];
+        mb[34 * 64 + lane] = lrun[0];
+        mb[35 * 64 + lane] = lrun[1];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const float m1 = mb[(32 + qs) * 64 + lane], l1 = mb[(34 + qs) * 64 + lane];
+            const float m = fmaxf(mrun[qs], m1);
+            const float a0 = exp2f((mrun[qs] - m) * L2E), a1 = exp2f((m1 - m) * L2E);
+            const float inv = 1.0f / (lrun[qs] * a0 + l1 * a1);
+            const int q = q0 + qs * 16 + l15;
+            if (q < N) {
+                bf16_t* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = (o[dt][qs][r] * a0 + mb[((dt * 2 + qs) * 4 + r) * 64 + lane] * a1) * inv;
+                    store4(dst + dt * 16, v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp, int H,
+                                    int N, int Npad, const int* kv_lens, int nbatch_lens) {
+    constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(Bp * H, (N + 127) / 128);
+    hipLaunchKernelGGL(attn2_fwd_kernel, grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens);
+    return hipGetLastError();
+}
+
+// precision dispatch: bf16 -> v2 (this file), f32 -> attn.h
+inline hipError_t launch_attention_any(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp,
+                                       int H, int N, int Npad, const int* kv_lens, int nbl) {
+    return launch_attention_bf16_v2(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl);
+}
+inline hipError_t launch_attention_any(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H,
+                                       int N, int Npad, const int* kv_lens, int nbl) {
+    return launch_attention<float>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl);
+}
+
+}  // namespace f5

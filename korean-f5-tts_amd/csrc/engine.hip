@@ -25,7 +25,7 @@
 #include <vector>
 
 #include "internal.h"
-#include "attn.h"
+#include "attn2.h"
 #include "convpos.h"
 #include "elementwise.h"
 #include "gemm_dispatch.h"
@@ -639,7 +639,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, 0.125f}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
-        HIPCHK(launch_attention<T>(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,

@@ -22,9 +22,10 @@ namespace f5 {
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // torch: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    // 0.5 (1 + tanh u) == sigmoid(2u) == 1 / (1 + exp(-2u)): one v_exp + one v_rcp instead of a tanhf expansion
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    return x * __frcp_rn(1.0f + __expf(-2.0f * u));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

@@ -21,10 +21,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi>
+// MODE (diagnostic builds only): 0 = normal, 1 = LDS-DMA only (no fragment reads / MFMA), 2 = compute only (no DMA
+// in the K loop): the two floors of the pipeline.
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
                                                                    const T* __restrict__ W, int ldw, int M, int N, int K,
-                                                                   Epi epi) {
+                                                                   Epi epi, int xa, int xb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WM * WN;
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
@@ -40,7 +42,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroup ids are dealt round-robin over the 8 XCDs (id % 8 labels the XCD's share); give
+    // each share a compact xa x xb rectangle of output tiles so that the A rows / W rows it touches fit its private L2.
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (xa > 0) {
+        const int tiles_n = gridDim.x;
+        const int bid = blockIdx.y * tiles_n + blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;          // idx-th tile of this XCD's share
+        const int rects_n = tiles_n / xb;                 // rectangles per row of rectangles
+        const int per_rect = xa * xb;
+        const int rect = xcd + 8 * (idx / per_rect), in = idx % per_rect;
+        tile_m = (rect / rects_n) * xa + in / xb;
+        tile_n = (rect % rects_n) * xb + in % xb;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nkt = K / KT;
     const bool transposed = epi.tile_transposed(n0);
 
@@ -85,14 +100,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
 
     int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        wait_vmcnt<(NS - 2) * L>();       // this wave's pieces of tile kt have landed ...
+        if (MODE != 2) wait_vmcnt<(NS - 2) * L>();  // this wave's pieces of tile kt have landed ...
         __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
         int pf = stage + NS - 1;
         if (pf >= NS) pf -= NS;
-        issue(kt + NS - 1, pf);
+        if (MODE != 2) issue(kt + NS - 1, pf);
         const char* sb = smem + stage * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < (MODE == 1 ? 0 : 2); ++kk) {
             const int co = kk ? c1 : c0;
             u32x4 af[MI], wf[NJ];
 #pragma unroll
@@ -139,20 +154,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi>
+// chooses (xa, xb): tiles_m % xa == 0, tiles_n % xb == 0 and the number of rectangles a multiple of 8; prefers the most
+// square rectangle with xa * xb close to one XCD's share of a full wave of workgroups (32 CUs).  (0, 0) = keep order.
+inline int& xcd_mode() { static int m = 1; return m; }
+inline void pick_xcd_rect(int tiles_m, int tiles_n, int* xa, int* xb) {
+    *xa = *xb = 0;
+    if (!xcd_mode()) return;
+    long best = -1;
+    for (int a = 1; a <= tiles_m && a <= 16; ++a) {
+        if (tiles_m % a) continue;
+        for (int b = 1; b <= tiles_n && b <= 32; ++b) {
+            if (tiles_n % b) continue;
+            const long rects = (long)(tiles_m / a) * (tiles_n / b);
+            if (rects % 8) continue;
+            const int area = a * b;
+            if (area > 64) continue;
+            // score: prefer area near 32, then small perimeter (a + b)
+            const long score = 1000L * (64 - (area > 32 ? area - 32 : 32 - area)) - 10L * (a + b);
+            if (score > best) { best = score; *xa = a; *xb = b; }
+        }
+    }
+    if (*xa * *xb <= 1) *xa = *xb = 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                    const Epi& epi) {
     constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
-                       ldw, M, N, K, epi);
+    // rectangle of tiles per XCD share: valid only when the grid splits into whole rectangles, 8 at a time
+    int xa = 0, xb = 0;
+    pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
+    hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
+                       ldw, M, N, K, epi, xa, xb);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@
 // synchronises the stream before returning.
 #include <vector>
 
-#include "attn.h"
+#include "attn2.h"
 #include "convpos.h"
 #include "elementwise.h"
 #include "gemm_dispatch.h"
@@ -125,7 +125,7 @@ static int attn_impl(const float* q, const float* k, const float* v, const int32
     hipLaunchKernelGGL((pack_qkv_test_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, q, k, v, qd.p, kd.p, vd.p, rows,
                        N, Npad, 0.125f);
     KCHK();
-    HIPCHK(launch_attention<T>(s, qd.p, kd.p, vd.p, od.p, Bp, H, N, Npad, lens_host ? ld.p : nullptr, Bp));
+    HIPCHK(launch_attention_any(s, qd.p, kd.p, vd.p, od.p, Bp, H, N, Npad, lens_host ? ld.p : nullptr, Bp));
     hipLaunchKernelGGL((to_f32_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, od.p, out, rows * 64);
     KCHK();
     HIPCHK(hipStreamSynchronize(s));
@@ -195,6 +195,13 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         case 7: return launch_gemm2_cfg<T, 128, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 8: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 9: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        // diagnostic floors of config 2 / 6 / 8 (outputs are garbage): 1xx = DMA only, 2xx = compute only
+        case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
+        case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 106: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
+        case 206: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 108: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
+        case 208: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
         default: return hipErrorInvalidValue;
     }
 }
@@ -230,6 +237,7 @@ static int gemm2_impl(const float* A, const float* W, const float* bias, int act
 }
 
 // experimental entry (not in the public header): v2 GEMM with config id; optional timing over `iters` launches
+extern "C" int f5x_set_xcd_mode(int32_t on) { xcd_mode() = on; return 0; }
 extern "C" int f5x_gemm2(int32_t prec, const float* A, const float* W, const float* bias, int32_t act, float* out, int32_t M,
                          int32_t N, int32_t K, int32_t cfg, int32_t iters, float* avg_us, f5_stream stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % 4)) return fail(F5_EINVAL, "f5x_gemm2: bad arguments");

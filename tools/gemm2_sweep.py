@@ -14,6 +14,8 @@ dev = "cuda:0"
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfgs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(10))
+if len(sys.argv) > 3:
+    lib.f5x_set_xcd_mode(int(sys.argv[3]))
 names = {0: "128x128 4w ns3", 1: "128x128 4w ns4", 2: "128x128 8w(2x4) ns4", 3: "128x64 4w ns4", 4: "128x64 4w ns3",
          5: "64x64 4w ns4", 6: "256x128 8w ns3", 7: "128x128 8w(4x2) ns3", 8: "64x64 4w ns3", 9: "128x64 8w ns4"}
 shapes = [("qkv", M, 3072, 1024), ("out", M, 1024, 1024), ("ff1", M, 2048, 1024), ("ff2", M, 1024, 2048), ("odd", 300, 100, 768)]
