@@ -70,7 +70,9 @@ def cpu_baseline(P, args, sd, vsd, cond, text):
     from oracle import f5_oracle as O
 
     arch = P.config.F5TTS_BASE
-    cores = torch.get_num_threads()
+    # a one-GPU box owns a 16-core share of the host (more threads than that only oversubscribe it)
+    cores = int(os.environ.get("F5_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
+    torch.set_num_threads(cores)
     N = args.frames
     gen = N - args.ref_frames
     with torch.no_grad():
@@ -123,7 +125,7 @@ def main():
     kw = dict(steps=args.nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
     gather_buf = None
     if world > 1:
-        gather_buf = torch.empty(world, B, gen, 100, device=dev)
+        gather_buf = torch.empty(world * B, gen, 100, device=dev)
 
     def step():
         out, _traj = model.sample(cond, text, N, **kw)
