@@ -107,6 +107,46 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------ UNetT glue
+// x[b', 0, :] = t_emb[b' or shared]; x[b', 1 + n, :] = h[b', n, :]      (unett.py:244: cat([t[:, None], x], dim=1))
+static __global__ void unett_assemble_kernel(const float* __restrict__ h, const float* __restrict__ temb, int temb_stride,
+                                             float* __restrict__ x, int Bp, int N, int D) {
+    const int d4 = D / 4;
+    const long total = (long)Bp * (N + 1) * d4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d4);
+        const long row = i / d4;
+        const int n = (int)(row % (N + 1)), b = (int)(row / (N + 1));
+        const float4 v = n == 0 ? reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride)[c]
+                                : reinterpret_cast<const float4*>(h + ((size_t)b * N + (n - 1)) * D)[c];
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+}
+// out[r, :] = [x[r, :] | skip[r, :]] converted to T   (unett.py:266: cat((x, skip), dim=-1))
+template <typename T>
+__global__ void cat2_kernel(const float* __restrict__ x, const float* __restrict__ skip, T* __restrict__ out, long rows, int D) {
+    const int d4 = D / 4;
+    const long total = rows * 2 * d4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (2 * d4));
+        const long r = i / (2 * d4);
+        const float4 v = c < d4 ? reinterpret_cast<const float4*>(x + r * D)[c]
+                                : reinterpret_cast<const float4*>(skip + r * D)[c - d4];
+        store4(out + r * 2 * D + (size_t)c * 4, v.x, v.y, v.z, v.w);
+    }
+}
+// pred[b', n, :] = pred_all[b', 1 + n, :]     (unett.py:278: norm_out(x)[:, 1:, :])
+static __global__ void strip_first_token_kernel(const float* __restrict__ in, float* __restrict__ out, int Bp, int N, int C) {
+    const int c4 = C / 4;
+    const long total = (long)Bp * N * c4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4);
+        const long row = i / c4;
+        const int n = (int)(row % N), b = (int)(row / N);
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(in + ((size_t)b * (N + 1) + n + 1) * C)[c];
+    }
+}
+
 // ------------------------------------------------------------------------------------- CFG + Euler update
 // y += dt * (p + (p - u) * cfg)   (cfm.py:190-191 + fixed-grid Euler, f5_tts_trtllm.py:360-369); also emits the new
 // state into the trajectory slot.  pred holds [cond half ; uncond half] when cfg is on.

@@ -437,8 +437,9 @@ template <typename T> struct Work {
     T* acat;
     float *h, *c1, *x, *pred;
     T *xn, *q, *k, *vt, *ao, *ffh;
-    T* cat2;       // UNetT concat buffer [rows, 2D]
-    float* skips;  // UNetT skip stack
+    T* cat2;         // UNetT concat buffer [rows, 2D]
+    float* skips;    // UNetT skip stack
+    float* pred_all; // UNetT proj_out over N+1 tokens
     int Npad;
 };
 
@@ -477,9 +478,11 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.ffh = a.take<T>(rows * F);
     w.cat2 = nullptr;
     w.skips = nullptr;
+    w.pred_all = nullptr;
     if (c.backbone == F5_BACKBONE_UNETT) {
         w.cat2 = a.take<T>(rows * 2 * D);
         w.skips = a.take<float>(rows * D * (c.depth / 2));
+        w.pred_all = a.take<float>(rows * mel);
     }
     return align_up(a.off, 256) + 256;
 }
@@ -671,6 +674,112 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     return F5_OK;
 }
 
+// One UNetT forward over Bp packed rows (unett.py:217-280): time token prepended (N + 1 tokens per row), concat skip
+// connections, x_transformers RMSNorm, no AdaLN.  temb: time embedding rows ([1, D] shared when temb_stride == 0).
+template <typename T>
+static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N,
+                             const float* temb, int temb_stride, const int* lens_dev, int drop_cond_first,
+                             const float* text_first, const float* text_second, hipStream_t s) {
+    Packed<T>& P = packed<T>(e);
+    const f5_config& c = e->cfg;
+    const int D = c.dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim, H = c.heads;
+    const int Nt = N + 1;
+    const int rows_in = Bp * N, rows = Bp * Nt;
+    Prof& pr = e->prof;
+    auto gfl = [&](double r, double n, double k) { return 2.0 * r * n * k; };
+    pr.begin(PC_MISC, s);
+    hipLaunchKernelGGL((pack_input_kernel<T>), dim3(ew_blocks((long)rows_in * e->kin / 4)), dim3(256), 0, s, y, cond,
+                       text_first, text_second, w.acat, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first);
+    KCHK();
+    pr.end(s);
+    pr.begin(PC_GEMM, s, gfl(rows_in, D, e->kin));
+    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows_in, D, e->kin_pad,
+                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
+    pr.end(s);
+    const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
+    pr.begin(PC_CONV, s, conv_fl);   // unett.py:99-100: conv_pos_embed is called WITHOUT a mask
+    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, nullptr, B));
+    pr.end(s);
+    pr.begin(PC_CONV, s, conv_fl);
+    float* emb = w.skips;  // free until the layer loop pushes the first skip; conv input and output must not alias
+    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, emb, Bp, N, D, nullptr, B));
+    pr.end(s);
+    pr.begin(PC_MISC, s);
+    hipLaunchKernelGGL(unett_assemble_kernel, dim3(ew_blocks((long)rows * D / 4)), dim3(256), 0, s, emb, temb, temb_stride, w.x,
+                       Bp, N, D);
+    KCHK();
+    pr.end(s);
+    const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
+    const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;   // lens_dev holds len + 1 for UNetT
+    const int half = c.depth / 2;
+    for (int l = 0; l < c.depth; ++l) {
+        BlockW<T>& bw = P.blocks[l];
+        if (l < half) {
+            HIPCHK(hipMemcpyAsync(w.skips + (size_t)l * rows * D, w.x, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else {
+            const float* skip = w.skips + (size_t)(c.depth - 1 - l) * rows * D;   // LIFO (skips.pop())
+            pr.begin(PC_MISC, s);
+            hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, w.cat2,
+                               (long)rows, D);
+            KCHK();
+            pr.end(s);
+            pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
+            HIPCHK(launch_gemm<T>(s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
+                                  EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
+            pr.end(s);
+        }
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, 0.125f}));
+        pr.end(s);
+        pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B));
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows, D, inner));
+        HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+                              EpiGateRes{w.x, w.x, D, bw.out.b, nullptr, 0, Nt, lens_dev}));
+        pr.end(s);
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm2_g);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows, F, D));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows, D, F));
+        HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}));
+        pr.end(s);
+    }
+    pr.begin(PC_LN, s);
+    hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, P.norm_out_g);
+    KCHK();
+    pr.end(s);
+    pr.begin(PC_GEMM, s, gfl(rows, mel, D));
+    HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}));
+    pr.end(s);
+    pr.begin(PC_MISC, s);
+    hipLaunchKernelGGL(strip_first_token_kernel, dim3(ew_blocks((long)rows_in * mel / 4)), dim3(256), 0, s, w.pred_all, w.pred, Bp, N, mel);
+    KCHK();
+    pr.end(s);
+    return F5_OK;
+}
+
+// dispatches one backbone forward; `step_row` selects the time step's vectors inside the per-call tables
+template <typename T>
+static int run_backbone(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N, int step_row,
+                        int per_row_time, const int* lens_dev, int drop_cond_first, const float* text_first,
+                        const float* text_second, hipStream_t s) {
+    if (e->cfg.backbone == F5_BACKBONE_DIT)
+        return run_dit_forward<T>(e, w, y, cond, B, Bp, N, w.mod + (size_t)step_row * e->modN, per_row_time ? e->modN : 0,
+                                  lens_dev, drop_cond_first, text_first, text_second, s);
+    return run_unett_forward<T>(e, w, y, cond, B, Bp, N, w.temb + (size_t)step_row * e->cfg.dim, per_row_time ? e->cfg.dim : 0,
+                                lens_dev, drop_cond_first, text_first, text_second, s);
+}
+
 // lens bookkeeping: uploads per-sample lengths (duplicated for the uncond half) through pinned staging
 template <typename T>
 static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, const int32_t* lens_host, int B,
@@ -686,7 +795,8 @@ static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, c
         HIPCHK(hipMemcpyAsync(w.tdev, th, (size_t)nT * 4, hipMemcpyHostToDevice, s));
     }
     if (lens_host) {
-        for (int i = 0; i < B; ++i) lh[i] = lh[B + i] = lens_host[i];
+        const int add = e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0;  // UNetT masks are left-padded for the time token
+        for (int i = 0; i < B; ++i) lh[i] = lh[B + i] = lens_host[i] + add;
         HIPCHK(hipMemcpyAsync(w.lens, lh, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
     }
     return F5_OK;
@@ -707,7 +817,8 @@ static int text_embed_impl(f5_engine* e, const int64_t* text, int B, int nt, con
     Work<T> w;
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     CHK(upload_small<T>(e, w, nullptr, 0, lens_host, B, s));
-    return run_text_embed<T>(e, w, text, B, nt, lens_host ? w.lens : nullptr, N, drop_text, out, s);
+    const bool per_sample = lens_host && e->cfg.backbone == F5_BACKBONE_DIT;  // unett.py embeds at the padded length
+    return run_text_embed<T>(e, w, text, B, nt, per_sample ? w.lens : nullptr, N, drop_text, out, s);
 }
 
 extern "C" int f5_text_embed(f5_engine* e, const int64_t* text, int32_t B, int32_t nt, const int32_t* lens_host,
@@ -723,7 +834,6 @@ template <typename T>
 static int forward_impl(f5_engine* e, const float* x, const float* cond, const int64_t* text, int nt,
                         const float* time_host, const int32_t* lens_host, int B, int N, int cfg_infer,
                         int drop_audio_cond, int drop_text, float* out, hipStream_t s) {
-    if (e->cfg.backbone != F5_BACKBONE_DIT) return fail(F5_EINVAL, "f5_dit_forward: UNetT forward goes through f5_sample");
     const int Bp = cfg_infer ? 2 * B : B;
     CHK(ensure_arena(e, B, N, Bp));
     Work<T> w;
@@ -733,13 +843,15 @@ static int forward_impl(f5_engine* e, const float* x, const float* cond, const i
     CHK(upload_small<T>(e, w, tt.data(), Bp, lens_host, B, s));
     const int* lens_dev = lens_host ? w.lens : nullptr;
     CHK(run_time_path<T>(e, w, Bp, s));
+    // UNetT embeds text at the padded length for every sample (unett.py:196-215), DiT at each sample's own length
+    const int* tlens = e->cfg.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
     if (cfg_infer) {
-        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 0, w.text_c, s));
-        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 1, w.text_u, s));
-        CHK(run_dit_forward<T>(e, w, x, cond, B, Bp, N, w.mod, e->modN, lens_dev, 0, w.text_c, w.text_u, s));
+        CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
+        CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
+        CHK(run_backbone<T>(e, w, x, cond, B, Bp, N, 0, 1, lens_dev, 0, w.text_c, w.text_u, s));
     } else {
-        CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, drop_text, w.text_c, s));
-        CHK(run_dit_forward<T>(e, w, x, cond, B, Bp, N, w.mod, e->modN, lens_dev, drop_audio_cond, w.text_c, w.text_c, s));
+        CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, drop_text, w.text_c, s));
+        CHK(run_backbone<T>(e, w, x, cond, B, Bp, N, 0, 1, lens_dev, drop_audio_cond, w.text_c, w.text_c, s));
     }
     HIPCHK(hipMemcpyAsync(out, w.pred, (size_t)Bp * N * e->cfg.mel_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
     return F5_OK;
@@ -760,7 +872,6 @@ template <typename T>
 static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
                        int nt, const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N,
                        float* out, float* traj, hipStream_t s) {
-    if (e->cfg.backbone != F5_BACKBONE_DIT) return fail(F5_EINVAL, "UNetT sampling is not built yet");
     const f5_config& c = e->cfg;
     const int mel = c.mel_dim;
     const bool use_cfg = !(cfg_strength < 1e-5f);
@@ -778,14 +889,14 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     KCHK();
     e->prof.end(s);
     CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
-    CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 0, w.text_c, s));
-    if (use_cfg) CHK(run_text_embed<T>(e, w, text, B, nt, lens_dev, N, 1, w.text_u, s));
+    const int* tlens = c.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
+    CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
+    if (use_cfg) CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
     float* y = out;  // ODE state lives in the caller's output buffer
     if (y != y0) HIPCHK(hipMemcpyAsync(y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (traj) HIPCHK(hipMemcpyAsync(traj, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int i = 0; i < steps; ++i) {
-        CHK(run_dit_forward<T>(e, w, y, w.step_cond, B, Bp, N, w.mod + (size_t)i * e->modN, 0, lens_dev, 0, w.text_c,
-                               use_cfg ? w.text_u : w.text_c, s));
+        CHK(run_backbone<T>(e, w, y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s));
         const float dt = t_host[i + 1] - t_host[i];
         e->prof.begin(PC_MISC, s);
         hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, y, w.pred, half, dt, cfg_strength,

@@ -17,7 +17,7 @@ TOL_PARITY = 1e-3   # BASELINE.json north_star: "within 1e-3 mel L-inf"
 TOL_BF16 = 8e-2     # bf16 operands (8-bit mantissa) through depth x NFE compounding; reported, loosely gated
 
 CASES = ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_b1_editmask", "sample_b1_norefaudio",
-         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp"]
+         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp", "sample_unett_b2"]
 
 
 def build_cfm(meta, sd, precision):
@@ -53,7 +53,7 @@ def test_sample_parity_f32_vs_reference_vectors(name):
     assert e_traj < TOL_PARITY and e_out < TOL_PARITY
 
 
-@pytest.mark.parametrize("name", ["sample_b1_nfe16", "sample_b3_masked"])
+@pytest.mark.parametrize("name", ["sample_b1_nfe16", "sample_b3_masked", "sample_unett_b2"])
 def test_sample_bf16_error_is_bounded_and_reported(name):
     meta, a = load_golden(name)
     sd = synthetic_weights(meta)
