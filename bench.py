@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--ref-frames", type=int, default=256)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2: B=1 N=1024 NFE=16 (default, the metric's config); c3: B=32 variable-length padded NFE=32; "
+                         "c5: E2-TTS UNetT B=8 NFE=16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="Euler steps timed on the host for cpu_baseline")
@@ -55,12 +58,23 @@ def dit_flops_per_seq_forward(N, D=1024, depth=22, F=2048, Dt=512, mel=100):
 
 
 def make_inputs(P, args, rank):
+    """SURVEY.md section 8(d) synthetic inputs.  Returns cond [B, ref_max, 100], text [B, nt], durations, ref lens."""
     g = torch.Generator().manual_seed(1 + rank)
     B = args.batch
-    cond = torch.randn(B, args.ref_frames, 100, generator=g)
-    nt = round(0.15 * args.frames)
-    text = torch.randint(1, P.config.VOCAB_SIZE - 1, (B, nt), generator=g)
-    return cond, text
+    if args.workload == "c3":
+        gl = torch.Generator().manual_seed(1234 + rank)
+        durs = [args.frames] + [int(x) for x in torch.randint(384, args.frames + 1, (B - 1,), generator=gl)]
+    else:
+        durs = [args.frames] * B
+    refs = [d // 4 for d in durs] if args.workload == "c3" else [args.ref_frames] * B
+    cond = torch.zeros(B, max(refs), 100)
+    for i, r in enumerate(refs):
+        cond[i, :r] = torch.randn(r, 100, generator=g)
+    nts = [round(0.15 * d) for d in durs]
+    text = torch.full((B, max(nts)), -1, dtype=torch.long)
+    for i, n in enumerate(nts):
+        text[i, :n] = torch.randint(1, P.config.VOCAB_SIZE - 1, (n,), generator=g)
+    return cond, text, durs, refs
 
 
 def cpu_baseline(P, args, sd, vsd, cond, text):
@@ -98,6 +112,10 @@ def cpu_baseline(P, args, sd, vsd, cond, text):
 
 def main():
     args = parse()
+    if args.workload == "c3":
+        args.batch, args.nfe = (32 if args.batch == 1 else args.batch), (32 if args.nfe == 16 else args.nfe)
+    if args.workload == "c5":
+        args.batch = 8 if args.batch == 1 else args.batch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,28 +129,38 @@ def main():
 
     import f5_tts_amd as P
 
-    arch = P.config.F5TTS_BASE
     nv = P.config.VOCAB_SIZE + 1  # load_model: text_num_embeds = vocab_size + 1 (utils_infer.py:313-317)
-    tr = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
+    if args.workload == "c5":
+        arch = P.config.E2TTS_BASE
+        tr = P.UNetT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
+    else:
+        arch = P.config.F5TTS_BASE
+        tr = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
     model = P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(dev)
     voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
-    cond_cpu, text_cpu = make_inputs(P, args, rank)
+    cond_cpu, text_cpu, durs, refs = make_inputs(P, args, rank)
     cond, text = cond_cpu.to(dev), text_cpu.to(dev)
     eng = tr.engine()
     eng.reserve(args.batch, args.frames, args.nfe)
     N, ref, B = args.frames, args.ref_frames, args.batch
     gen = N - ref
+    gen_frames_total = sum(d - r for d, r in zip(durs, refs))
     kw = dict(steps=args.nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
+    uniform = len(set(durs)) == 1 and len(set(refs)) == 1
+    dur_t = N if uniform else torch.tensor(durs)
+    lens_t = None if uniform else torch.tensor(refs)
     gather_buf = None
     if world > 1:
-        gather_buf = torch.empty(world * B, gen, 100, device=dev)
+        gather_buf = torch.empty(world * B, N, 100, device=dev)
 
     def step():
-        out, _traj = model.sample(cond, text, N, **kw)
-        mel_gen = out[:, ref:, :]
-        wav = voc.decode(mel_gen.permute(0, 2, 1))
+        out, _traj = model.sample(cond, text, dur_t, lens=lens_t, **kw)
+        if uniform:
+            wav = voc.decode(out[:, ref:, :].permute(0, 2, 1))
+        else:  # per item, as the reference's harness does (eval_infer_batch.py:202-206): own prompt / total length
+            wav = [voc.decode(out[i:i + 1, refs[i]:durs[i], :].permute(0, 2, 1)) for i in range(B)][-1]
         if world > 1:
-            dist.all_gather_into_tensor(gather_buf, mel_gen.contiguous())
+            dist.all_gather_into_tensor(gather_buf, out.contiguous())
         return out, wav
 
     def barrier():
@@ -154,7 +182,7 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out).all() and torch.isfinite(wav).all()
 
-    audio_per_step = B * gen * 256 / 24000
+    audio_per_step = gen_frames_total * 256 / 24000
     value = audio_per_step * args.steps * world / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -164,8 +192,12 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "rtf_wall_over_audio": 1.0 / value * world,  # per-utterance RTF in the reference's convention (wall / audio)
-        "config": {"workload": "C2: F5-TTS Base, 1 utterance/rank/step, prompt %d + generated %d mel frames, NFE=%d EPSS, "
-                               "cfg 2.0, sway -1, Vocos decode, mel all_gather when n_gpus>1" % (ref, gen, args.nfe),
+        "config": {"workload": {"c2": "C2: F5-TTS Base, 1 utterance/rank/step, prompt %d + generated %d mel frames, NFE=%d EPSS, "
+                                      "cfg 2.0, sway -1, Vocos decode, mel all_gather when n_gpus>1" % (ref, gen, args.nfe),
+                                "c3": "C3: F5-TTS Base, %d variable-length utterances/rank/step padded to %d frames (prompt = len/4), "
+                                      "NFE=%d, cfg 2.0, sway -1, per-item Vocos decode" % (B, N, args.nfe),
+                                "c5": "C5: E2-TTS UNetT Base, %d utterances/rank/step, prompt %d + generated %d frames, NFE=%d, cfg 2.0, "
+                                      "sway -1, Vocos decode (BigVGAN is not built)" % (B, ref, gen, args.nfe)}[args.workload],
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }
@@ -175,7 +207,7 @@ def main():
         # dedicated pass over the same workload right after the timed region
         if not args.no_profile:
             eng.profile(True)
-            model.sample(cond, text, N, **kw)
+            model.sample(cond, text, dur_t, lens=lens_t, **kw)
             torch.cuda.synchronize()
             prof = eng.profile_read()
             eng.profile(False)
@@ -192,9 +224,10 @@ def main():
                 k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                     "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None}
                 for k, v in prof.items()}
-            total_fl = 2 * args.nfe * dit_flops_per_seq_forward(N) * B
-            result["whole_path_tflops"] = total_fl / (ms_per_step * 1e-3) / 1e12
-        if world == 1 and not args.no_cpu_baseline:
+            if args.workload != "c5":  # algorithmic FLOPs on VALID tokens only, so padding waste shows as lost efficiency
+                total_fl = 2 * args.nfe * sum(dit_flops_per_seq_forward(d) for d in durs)
+                result["whole_path_tflops"] = total_fl / (ms_per_step * 1e-3) / 1e12
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             try:
                 result["cpu_baseline"] = cpu_baseline(P, args, tr.state_dict(), voc.state_dict(), cond_cpu, text_cpu)
             except Exception as ex:  # the baseline is a report, never a reason to lose the bench line
