@@ -40,18 +40,33 @@ template <> struct Mma<float> {
 };
 
 // ---------------------------------------------------------------------------------------------- epilogues
-// row4(m, n, v): v[r] = C[m][n + r]           (row-packed orientation; n % 4 == 0)
-// col4(m, n, v): v[r] = C[m + r][n]           (transposed orientation; m % 4 == 0) -- only if tile_transposed()
+// An epilogue splits its per-element work into a ROW context (computed once per output row a lane touches: batch
+// index, position, masks -- this is where the integer divisions live), a COLUMN context (once per 4-column group:
+// bias, head, ...) and a store that combines them:
+//   RowCtx row(m) / ColCtx col(n)                      row-packed orientation: v[r] = C[m][n + r]      (n % 4 == 0)
+//   void   store(RowCtx, ColCtx, v)
+//   TRowCtx trow(m, M) / TColCtx tcol(n)               transposed orientation: v[r] = C[m + r][n]      (m % 4 == 0)
+//   void   tstore(TRowCtx, TColCtx, v)                 -- only reached if tile_transposed() can be true
+struct NoCtx {};
 
 template <typename TO> struct EpiStore {  // out = act(acc + bias)
     TO* out; int ldo; const float* bias; int act;
+    struct RowCtx { TO* p; };
+    struct ColCtx { float4 b; int n; };
+    typedef NoCtx TRowCtx;
+    typedef NoCtx TColCtx;
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
-    __device__ __forceinline__ void row4(int m, int n, f32x4 v, int, int) const {
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        store4(out + (size_t)m * ldo + n, apply_act(v[0] + b.x, act), apply_act(v[1] + b.y, act),
-               apply_act(v[2] + b.z, act), apply_act(v[3] + b.w, act));
+    __device__ __forceinline__ RowCtx row(int m) const { return {out + (size_t)m * ldo}; }
+    __device__ __forceinline__ ColCtx col(int n) const {
+        return {bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0), n};
     }
-    __device__ __forceinline__ void col4(int, int, f32x4, int, int) const {}
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v) const {
+        store4(r.p + c.n, apply_act(v[0] + c.b.x, act), apply_act(v[1] + c.b.y, act), apply_act(v[2] + c.b.z, act),
+               apply_act(v[3] + c.b.w, act));
+    }
+    __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
+    __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
+    __device__ __forceinline__ void tstore(const NoCtx&, const NoCtx&, f32x4) const {}
 };
 
 // x[m][n] = res[m][n] + gate[b(m)][n] * (acc + bias)    (res may alias x; gate == nullptr -> 1; rows m with
@@ -60,59 +75,84 @@ template <typename TO> struct EpiStore {  // out = act(acc + bias)
 struct EpiGateRes {
     float* x; const float* res; int ld; const float* bias; const float* gate; int gate_stride; int rows_per_batch;
     const int* lens;
+    struct RowCtx { size_t off; const float* g; bool masked; };
+    struct ColCtx { float4 b; int n; };
+    typedef NoCtx TRowCtx;
+    typedef NoCtx TColCtx;
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
-    __device__ __forceinline__ void row4(int m, int n, f32x4 v, int, int) const {
+    __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / rows_per_batch;
-        float4 r = *reinterpret_cast<const float4*>(res + (size_t)m * ld + n);
-        if (!(lens && (m - b * rows_per_batch) >= lens[b])) {
-            float4 bi = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-            float4 g = gate ? *reinterpret_cast<const float4*>(gate + (size_t)b * gate_stride + n)
-                            : make_float4(1, 1, 1, 1);
-            r.x += g.x * (v[0] + bi.x); r.y += g.y * (v[1] + bi.y);
-            r.z += g.z * (v[2] + bi.z); r.w += g.w * (v[3] + bi.w);
-        }
-        *reinterpret_cast<float4*>(x + (size_t)m * ld + n) = r;
+        return {(size_t)m * ld, gate ? gate + (size_t)b * gate_stride : nullptr,
+                lens ? (m - b * rows_per_batch) >= lens[b] : false};
     }
-    __device__ __forceinline__ void col4(int, int, f32x4, int, int) const {}
+    __device__ __forceinline__ ColCtx col(int n) const {
+        return {bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0), n};
+    }
+    __device__ __forceinline__ void store(const RowCtx& rc, const ColCtx& c, f32x4 v) const {
+        float4 r = *reinterpret_cast<const float4*>(res + rc.off + c.n);
+        if (!rc.masked) {
+            const float4 g = rc.g ? *reinterpret_cast<const float4*>(rc.g + c.n) : make_float4(1, 1, 1, 1);
+            r.x += g.x * (v[0] + c.b.x); r.y += g.y * (v[1] + c.b.y);
+            r.z += g.z * (v[2] + c.b.z); r.w += g.w * (v[3] + c.b.w);
+        }
+        *reinterpret_cast<float4*>(x + rc.off + c.n) = r;
+    }
+    __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
+    __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
+    __device__ __forceinline__ void tstore(const NoCtx&, const NoCtx&, f32x4) const {}
 };
 
 // Fused QKV projection epilogue (modules.py:469-497): bias, interleaved-pair rotary on the first `pe_heads` heads of
 // q and k, q pre-scaled by dim_head^-0.5, head split.  q,k -> [B', H, Nseq, 64]; v -> TRANSPOSED [B', H, 64, Npad]
-// (so that both attention B-operands are K-contiguous).  Column tiles of the V third use the transposed orientation.
+// (so that both attention B-operands are K-contiguous).  16-column sub-tiles of the V third use the transposed
+// orientation.
 template <typename TO> struct EpiQKV {
     TO* q; TO* k; TO* vt; const float* bias; const float* rope_cos; const float* rope_sin;  // [maxpos][32]
     int Nseq, Npad, H, pe_heads; float q_scale;
+    struct RowCtx { size_t base; const float* cs; const float* sn; };      // base = (b*H*Nseq + pos) * 64
+    struct ColCtx { float4 b; TO* dst; size_t hoff; int d; bool rot; float scale; };
+    struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
+    struct TColCtx { float b; size_t hoff; };
     __device__ __forceinline__ bool tile_transposed(int n0) const { return n0 >= 2 * H * 64; }
-    __device__ __forceinline__ void row4(int m, int n, f32x4 v, int, int) const {
-        const int inner = H * 64;
-        const int which = n / inner, c = n - which * inner, h = c >> 6, d = c & 63;
+    __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / Nseq, pos = m - b * Nseq;
-        const float4 bi = *reinterpret_cast<const float4*>(bias + n);
-        float a0 = v[0] + bi.x, a1 = v[1] + bi.y, a2 = v[2] + bi.z, a3 = v[3] + bi.w;
-        if (h < pe_heads) {
-            const float2 cs = *reinterpret_cast<const float2*>(rope_cos + pos * 32 + (d >> 1));
-            const float2 sn = *reinterpret_cast<const float2*>(rope_sin + pos * 32 + (d >> 1));
+        return {((size_t)b * H * Nseq + pos) * 64, rope_cos + pos * 32, rope_sin + pos * 32};
+    }
+    __device__ __forceinline__ ColCtx col(int n) const {
+        const int inner = H * 64;
+        const int which = n >= inner ? 1 : 0, c = n - which * inner, h = c >> 6, d = c & 63;
+        return {*reinterpret_cast<const float4*>(bias + n), which ? k : q, (size_t)h * Nseq * 64 + d, d, h < pe_heads,
+                which ? 1.0f : q_scale};
+    }
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v) const {
+        float a0 = v[0] + c.b.x, a1 = v[1] + c.b.y, a2 = v[2] + c.b.z, a3 = v[3] + c.b.w;
+        if (c.rot) {
+            const float2 cs = *reinterpret_cast<const float2*>(r.cs + (c.d >> 1));
+            const float2 sn = *reinterpret_cast<const float2*>(r.sn + (c.d >> 1));
             const float r0 = a0 * cs.x - a1 * sn.x, r1 = a1 * cs.x + a0 * sn.x;
             const float r2 = a2 * cs.y - a3 * sn.y, r3 = a3 * cs.y + a2 * sn.y;
             a0 = r0; a1 = r1; a2 = r2; a3 = r3;
         }
-        TO* dst = which == 0 ? q : k;
-        if (which == 0) { a0 *= q_scale; a1 *= q_scale; a2 *= q_scale; a3 *= q_scale; }
-        store4(dst + (((size_t)b * H + h) * Nseq + pos) * 64 + d, a0, a1, a2, a3);
+        store4(c.dst + r.base + c.hoff, a0 * c.scale, a1 * c.scale, a2 * c.scale, a3 * c.scale);
     }
-    __device__ __forceinline__ void col4(int m, int n, f32x4 v, int M, int) const {
-        const int c = n - 2 * H * 64, h = c >> 6, d = c & 63;
-        const float bi = bias[n];
+    __device__ __forceinline__ TRowCtx trow(int m, int M) const {
         const int b = m / Nseq, pos = m - b * Nseq;
-        if ((pos & 3) == 0 && pos + 3 < Nseq) {
-            store4(vt + (((size_t)b * H + h) * 64 + d) * Npad + pos, v[0] + bi, v[1] + bi, v[2] + bi, v[3] + bi);
+        return {(size_t)b * H * 64 * Npad + pos, pos, b, (pos & 3) == 0 && pos + 3 < Nseq, m, M};
+    }
+    __device__ __forceinline__ TColCtx tcol(int n) const {
+        const int c = n - 2 * H * 64;  // = h*64 + d
+        return {bias[n], (size_t)c * Npad};
+    }
+    __device__ __forceinline__ void tstore(const TRowCtx& r, const TColCtx& c, f32x4 v) const {
+        if (r.fast) {
+            store4(vt + r.base + c.hoff, v[0] + c.b, v[1] + c.b, v[2] + c.b, v[3] + c.b);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mm = m + r;
-                if (mm < M) {
+            for (int rr = 0; rr < 4; ++rr) {
+                const int mm = r.m + rr;
+                if (mm < r.M) {
                     const int bb = mm / Nseq, pp = mm - bb * Nseq;
-                    vt[(((size_t)bb * H + h) * 64 + d) * Npad + pp] = from_f32<TO>(v[r] + bi);
+                    vt[(size_t)bb * H * 64 * Npad + c.hoff + pp] = from_f32<TO>(v[rr] + c.b);
                 }
             }
         }
@@ -205,23 +245,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, i
 
     const int mw = m0 + wr * (BM / 2), nw = n0 + wc * (BN / 2);
     if (!transposed) {
+        typename Epi::ColCtx cc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cc[j] = epi.col(min(nw + j * 16 + (lane >> 4) * 4, N - 4));
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mw + i * 16 + (lane & 15);
+            if (m >= M) continue;
+            const typename Epi::RowCtx rc = epi.row(m);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nw + j * 16 + (lane >> 4) * 4;
-                if (m < M && n < N) epi.row4(m, n, acc[i][j], M, N);
-            }
+            for (int j = 0; j < NJ; ++j)
+                if (nw + j * 16 + (lane >> 4) * 4 < N) epi.store(rc, cc[j], acc[i][j]);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mw + i * 16 + (lane >> 4) * 4;
+            if (m >= M) continue;
+            const typename Epi::TRowCtx rc = epi.trow(m, M);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = nw + j * 16 + (lane & 15);
-                if (m < M && n < N) epi.col4(m, n, acc[i][j], M, N);
+                if (n < N) epi.tstore(rc, epi.tcol(n), acc[i][j]);
             }
         }
     }

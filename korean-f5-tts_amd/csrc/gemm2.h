@@ -23,6 +23,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 
 // MODE (diagnostic builds only): 0 = normal, 1 = LDS-DMA only (no fragment reads / MFMA), 2 = compute only (no DMA
 // in the K loop): the two floors of the pipeline.
+// Fragment reads issued as inline asm so that hipcc does not wait lgkmcnt(0) before the first MFMA (it does for every
+// compiler-visible ds_read_b128 on this toolchain): the waits below are placed by hand with counted lgkmcnt(N); the
+// fragments a wait retires are threaded through it as "+v" operands, so no MFMA can be scheduled above its wait.
+__device__ __forceinline__ void lds_read_b128_asm(u32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
                                                                    const T* __restrict__ W, int ldw, int M, int N, int K,
@@ -57,7 +77,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nkt = K / KT;
-    const bool transposed = epi.tile_transposed(n0);
+    // orientation per 16-column sub-tile of this wave (wave-uniform): lets a block tile straddle the q|k -> v boundary
+    // (block tiles of 64/128/256 columns never straddle it: one flag for the whole block keeps the MFMA loop branch-free)
+    constexpr bool PERJ = (BN % 64) != 0 || BN == 192;
+    bool trj[NJ];
+    const bool tr_block = epi.tile_transposed(n0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) trj[j] = PERJ ? epi.tile_transposed(n0 + (wave % WN) * TN + j * 16) : tr_block;
 
     // per-lane source pointers for this wave's pieces (row inside the 8-row group = lane >> 3, swizzled chunk)
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
@@ -94,10 +120,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     const int a_row_off = (wr * TM + l15) * GEMM_ROW_BYTES;
     const int w_row_off = BM * GEMM_ROW_BYTES + (wc * TN + l15) * GEMM_ROW_BYTES;
     const int c0 = ((0 + g) ^ sw) * 16, c1 = ((4 + g) ^ sw) * 16;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of smem
 
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t, t);
 
+    // retire every scalar/LDS operation of the prologue: with nothing of another kind pending on the lgkm counter the
+    // compiler can use counted lgkmcnt(N) waits (in-order LDS returns) inside the loop instead of lgkmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (MODE != 2) wait_vmcnt<(NS - 2) * L>();  // this wave's pieces of tile kt have landed ...
@@ -106,24 +136,51 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
         if (pf >= NS) pf -= NS;
         if (MODE != 2) issue(kt + NS - 1, pf);
         const char* sb = smem + stage * STAGE;
+        if (MODE != 1) {
+            // all fragment reads of the K-tile are issued first, in the order the MFMAs consume them:
+            //   per kk: a[0], w[0..NJ-1], a[1..MI-1];  the MFMA row i of kk may start once read (kk*(MI+NJ) + NJ + i) is back
+            u32x4 af[2][MI], wf[2][NJ];
+            const unsigned sbu = (unsigned)(size_t)(sb - smem) + lds_base;
 #pragma unroll
-        for (int kk = 0; kk < (MODE == 1 ? 0 : 2); ++kk) {
-            const int co = kk ? c1 : c0;
-            u32x4 af[MI], wf[NJ];
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned co = kk ? c1 : c0;
+                lds_read_b128_asm(af[kk][0], sbu + a_row_off + co);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const u32x4*>(sb + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
+                for (int j = 0; j < NJ; ++j) lds_read_b128_asm(wf[kk][j], sbu + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const u32x4*>(sb + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
-            if (!transposed) {
+                for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
+            }
+            constexpr int R = 2 * (MI + NJ);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(wf[j], af[i], acc[i][j]);
-            } else {
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);  // keep the previous row's MFMAs above this wait
+                    // outstanding reads allowed when row i of kk starts
+                    if (kk == 0) {
+                        if (i == 0) { if constexpr (NJ == 2) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1]);
+                                      else if constexpr (NJ == 3) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1], wf[0][2]);
+                                      else if constexpr (NJ == 4) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1], wf[0][2], wf[0][3]);
+                                      else wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0]); }
+                        else if (i == 1) wait_lgkm<(R - 1 - (NJ + 1)) < 0 ? 0 : (R - 1 - (NJ + 1))>(af[0][i]);
+                        else if (i == 2) wait_lgkm<(R - 1 - (NJ + 2)) < 0 ? 0 : (R - 1 - (NJ + 2))>(af[0][i]);
+                        else wait_lgkm<(R - 1 - (NJ + 3)) < 0 ? 0 : (R - 1 - (NJ + 3))>(af[0][i]);
+                    } else {
+                        constexpr int B0 = MI + NJ;
+                        if (i == 0) { if constexpr (NJ == 2) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1]);
+                                      else if constexpr (NJ == 3) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1], wf[1][2]);
+                                      else if constexpr (NJ == 4) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1], wf[1][2], wf[1][3]);
+                                      else wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0]); }
+                        else if (i == 1) wait_lgkm<(R - 1 - (B0 + NJ + 1)) < 0 ? 0 : (R - 1 - (B0 + NJ + 1))>(af[1][i]);
+                        else if (i == 2) wait_lgkm<(R - 1 - (B0 + NJ + 2)) < 0 ? 0 : (R - 1 - (B0 + NJ + 2))>(af[1][i]);
+                        else wait_lgkm<(R - 1 - (B0 + NJ + 3)) < 0 ? 0 : (R - 1 - (B0 + NJ + 3))>(af[1][i]);
+                    }
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(af[i], wf[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) {
+                        if (!trj[j]) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);
+                        else acc[i][j] = Mma<T>::run(af[kk][i], wf[kk][j], acc[i][j]);
+                    }
+                }
             }
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
@@ -131,25 +188,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     wait_vmcnt<0>();  // drain the dummy tail loads before the block's LDS can be reallocated
 
     const int mw = m0 + wr * TM, nw = n0 + wc * TN;
-    if (!transposed) {
+    bool any_row = false, any_tr = false;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mw + i * 16 + l15;
+    for (int j = 0; j < NJ; ++j) { any_row |= !trj[j]; any_tr |= trj[j]; }
+    if (any_row) {
+        typename Epi::RowCtx rc[MI];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nw + j * 16 + g * 4;
-                if (m < M && n < N) epi.row4(m, n, acc[i][j], M, N);
-            }
+        for (int i = 0; i < MI; ++i) rc[i] = epi.row(min(mw + i * 16 + l15, M - 1));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nw + j * 16 + g * 4;
+            if (trj[j] || n >= N) continue;
+            const typename Epi::ColCtx cc = epi.col(n);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (mw + i * 16 + l15 < M) epi.store(rc[i], cc, acc[i][j]);
         }
-    } else {
+    }
+    if (any_tr) {
+        typename Epi::TRowCtx rc[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mw + i * 16 + g * 4;
+        for (int i = 0; i < MI; ++i) rc[i] = epi.trow(min(mw + i * 16 + g * 4, M - 1), M);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nw + j * 16 + l15;
-                if (m < M && n < N) epi.col4(m, n, acc[i][j], M, N);
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nw + j * 16 + l15;
+            if (!trj[j] || n >= N) continue;
+            const typename Epi::TColCtx cc = epi.tcol(n);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (mw + i * 16 + g * 4 < M) epi.tstore(rc[i], cc, acc[i][j]);
         }
     }
 }

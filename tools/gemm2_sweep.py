@@ -16,6 +16,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 cfgs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(10))
 if len(sys.argv) > 3:
     lib.f5x_set_xcd_mode(int(sys.argv[3]))
+if len(sys.argv) > 4:
+    lib.f5x_set_cold_weights(int(sys.argv[4]))
 names = {0: "128x128 4w ns3", 1: "128x128 4w ns4", 2: "128x128 8w(2x4) ns4", 3: "128x64 4w ns4", 4: "128x64 4w ns3",
          5: "64x64 4w ns4", 6: "256x128 8w ns3", 7: "128x128 8w(4x2) ns3", 8: "64x64 4w ns3", 9: "128x64 8w ns4"}
 shapes = [("qkv", M, 3072, 1024), ("out", M, 1024, 1024), ("ff1", M, 2048, 1024), ("ff2", M, 1024, 2048), ("odd", 300, 100, 768)]
@@ -30,7 +32,7 @@ for prec, pname, tol in ((1, "bf16", 1.5e-2), (0, "f32", 2e-5)):
         for cfg in cfgs:
             out = torch.zeros(m, n, device=dev)
             us = C.c_float(0)
-            rc = fn(prec, A.data_ptr(), W.data_ptr(), b.data_ptr(), 0, out.data_ptr(), m, n, k, cfg, 30 if name != "odd" else 0, C.byref(us), s)
+            rc = fn(prec, A.data_ptr(), W.data_ptr(), b.data_ptr(), 0, out.data_ptr(), m, n, k, cfg, 64 if name != "odd" else 0, C.byref(us), s)
             if rc != 0:
                 row.append(f"[{cfg}] ERR {lib.f5_last_error().decode()[:60]}")
                 continue

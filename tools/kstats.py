@@ -1,5 +1,5 @@
 import csv, sys, glob
-f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True))[-1]
+f = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else sorted(glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f, "total ms", tot / 1e6)
