@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="Euler steps timed on the host for cpu_baseline")
+    ap.add_argument("--setup-runs", type=int, default=3, help="untimed engine-initialisation runs before the warm-up")
     return ap.parse_args()
 
 
@@ -168,6 +169,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # engine setup (untimed, before the W warm-up steps): first-use work that is not part of a step -- arena growth,
+    # hipFuncSetAttribute on every kernel instantiation, RCCL communicator creation, clock ramp from the idle state
+    for _ in range(args.setup_runs):
+        step()
+    barrier()
     for _ in range(args.warmup):
         out, wav = step()
     barrier()
@@ -214,9 +220,15 @@ def main():
             gm, at = prof["gemm"], prof["attention"]
             peak = MFMA_PEAK_TFLOPS[args.precision]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if args.workload == "c2" and args.precision == "bf16" and os.path.exists(tfile):
+                # HBM-side bytes per launch of this kernel class, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+                # in separate passes over this same command (tools/pmc_bench.sh) and committed under profiles/
+                traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
             result["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_tn_kernel (all DiT projections / FFN, fused epilogues)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "bound": "mfma", "kernel": "gemm_tn_glds_kernel (all DiT projections / FFN, fused epilogues)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "flops_per_launch_avg": gm["flops"] / max(gm["launches"], 1),
             }
