@@ -11,7 +11,7 @@
  *   f5_dit_forward   <- DiT.forward / UNetT.forward                  model/backbones/dit.py:278-329, unett.py:217-280
  *   f5_text_embed    <- TextEmbedding.forward (+ per-sample loop)    model/backbones/dit.py:86-115,244-258
  *   f5_vocos_decode  <- vocoder.decode(mel)                          infer/utils_infer.py:702-703 (third-party vocos)
- *   f5_mel_spectrogram <- MelSpec.forward (vocos type)               model/modules.py:78-146
+ *   f5_mel_forward   <- MelSpec.forward (vocos type)                 model/modules.py:78-146
  *   f5_load_weight   <- load_checkpoint's state-dict assignment      infer/utils_infer.py:242-286
  * The reference-side binding (ctypes) is shown in INTEGRATION.md.
  */
@@ -125,6 +125,17 @@ int f5_vocos_load_weight(f5_vocos* v, const char* name, const void* dev_f32, con
 int f5_vocos_finalize(f5_vocos* v, f5_stream stream);
 /* mel f32[B, C, T] -> wav f32[B, (T - 1) * hop]   (Vocos.decode: backbone -> ISTFTHead, padding="center") */
 int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t T, float* wav, f5_stream stream);
+
+/* ------------------------------------------------------------------------------------- prompt mel front-end
+ * MelSpec.forward, mel_spec_type="vocos" (model/modules.py:78-146): wav f32[B, nw] -> log-mel f32[B, T, n_mels],
+ * T = nw / hop + 1.  Constant tables are host-computed and loaded once:
+ *   aux.dft_basis f32[round_up(2*(n_fft/2+1), 4), n_fft]  rows w*cos(2 pi f j / n_fft) for f <= n_fft/2, then w*sin(..)
+ *   aux.mel_fb    f32[n_mels, round_up(n_fft/2+1, 32)]    HTK mel filterbank, norm=None (torchaudio melscale_fbanks)   */
+typedef struct f5_mel f5_mel;
+int f5_mel_create(int32_t n_fft, int32_t hop_length, int32_t n_mels, f5_mel** out);
+int f5_mel_destroy(f5_mel* m);
+int f5_mel_load(f5_mel* m, const char* name, const void* dev_f32, const int64_t* shape, int32_t ndim, f5_stream stream);
+int f5_mel_forward(f5_mel* m, const float* wav, int32_t B, int32_t nw, float* out, f5_stream stream);
 
 /* ----------------------------------------------------------------------------- kernel-level entry points
  * Used by tests/ (parity of each kernel against a torch fp32 restatement) and by the micro-benchmarks.  fp32 in/out;

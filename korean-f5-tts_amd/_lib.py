@@ -51,6 +51,10 @@ SIGNATURES = {
     "f5_vocos_load_weight": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),
     "f5_vocos_finalize": (_i, [_p, _p]),
     "f5_vocos_decode": (_i, [_p, _p, _i, _i, _p, _p]),
+    "f5_mel_create": (_i, [_i, _i, _i, C.POINTER(_p)]),
+    "f5_mel_destroy": (_i, [_p]),
+    "f5_mel_load": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),
+    "f5_mel_forward": (_i, [_p, _p, _i, _i, _p, _p]),
     "f5k_gemm": (_i, [_i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "f5k_attention": (_i, [_i, _p, _p, _p, C.POINTER(_i), _p, _i, _i, _i, _p]),
     "f5k_convpos": (_i, [_i, _p, _p, _p, _p, C.POINTER(_i), _p, _i, _i, _i, _p]),

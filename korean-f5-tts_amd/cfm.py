@@ -44,6 +44,14 @@ class CFM(nn.Module):
     def forward(self, *a, **k):
         raise NotImplementedError("training (cfm.py:231-302) is outside the inference hot path")
 
+    def load_state_dict(self, sd, strict=True, assign=False):
+        """Accepts the reference's CFM state dict (`transformer.*` keys, optional `mel_spec.*` buffers): the backbone
+        keeps the weights; everything else in a CFM is parameter-free."""
+        return self.transformer.load_state_dict(sd, strict=strict)
+
+    def state_dict(self, *a, **k):
+        return {"transformer." + n: t for n, t in self.transformer.state_dict().items()}
+
     @torch.no_grad()
     def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
                seed: int | None = None, max_duration=65536, vocoder=None, use_epss=True, no_ref_audio=False,

@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // (operand precision ids F5_PREC_F32 / F5_PREC_BF16 live in include/f5_hip.h)
 // activation ids used by GEMM epilogues
-enum { F5_ACT_NONE = 0, F5_ACT_GELU_TANH = 1, F5_ACT_GELU_ERF = 2, F5_ACT_SILU = 3, F5_ACT_MISH = 4 };
+enum { F5_ACT_NONE = 0, F5_ACT_GELU_TANH = 1, F5_ACT_GELU_ERF = 2, F5_ACT_SILU = 3, F5_ACT_MISH = 4, F5_ACT_LOGCLAMP = 5 };
 
 namespace f5 {
 
@@ -40,6 +40,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case F5_ACT_GELU_ERF: return gelu_erf(v);
         case F5_ACT_SILU: return silu(v);
         case F5_ACT_MISH: return mish(v);
+        case F5_ACT_LOGCLAMP: return logf(fmaxf(v, 1e-5f));  // mel.clamp(min=1e-5).log(), modules.py:103
         default: return v;
     }
 }

@@ -1,0 +1,210 @@
+"""Inference harness around the hot path, with the reference's function names and behaviour
+(src/f5_tts/infer/utils_infer.py) -- SURVEY.md section 8(f) rows 1 and 3:
+
+  chunk_text                         utils_infer.py:83-110      text -> chunks of <= max_chars utf-8 bytes
+  convert_peft_state_dict_to_plain   utils_infer.py:198-239     PEFT/LoRA keys -> plain weights (W + B A * alpha / r)
+  load_checkpoint                    utils_infer.py:242-286     .pt / .safetensors, EMA prefix, legacy mel buffers
+  load_model                         utils_infer.py:292-345     CFM(model_cls(**cfg, text_num_embeds=vocab+1, mel_dim))
+  load_vocoder                       utils_infer.py:114-137     local vocos checkpoint only (no network here)
+  infer_batch_process / infer_process utils_infer.py:453-778    mono mix, RMS-to-0.1, duration formula, sample(),
+                                                                 prompt slicing, fp32 vocoder input, rescale, cross-fade
+
+Out of scope here: pydub silence clipping, Whisper ASR, resampling (torchaudio is absent:
+prompts must already be at 24 kHz), pinyin / Korean G2P tokenisers (text is tokenised per character through
+`vocab_char_map`, or as utf-8 bytes when the model has no vocabulary, exactly as CFM.sample does for list[str]).
+Only checkpoints are loaded with loaders that execute nothing from the file (safetensors, torch.load(weights_only=True)).
+"""
+from __future__ import annotations
+
+import re
+
+import numpy as np
+import torch
+
+from .cfm import CFM
+from .config import HOP_LENGTH, MEL_DIM, N_FFT, SAMPLE_RATE
+from .utils import load_vocab
+from .vocos import Vocos
+
+target_sample_rate = SAMPLE_RATE
+n_mel_channels = MEL_DIM
+hop_length = HOP_LENGTH
+win_length = N_FFT
+n_fft = N_FFT
+mel_spec_type = "vocos"
+target_rms = 0.1
+cross_fade_duration = 0.15
+ode_method = "euler"
+nfe_step = 32
+cfg_strength = 2.0
+sway_sampling_coef = -1.0
+speed = 1.0
+fix_duration = None
+
+
+def chunk_text(text: str, max_chars: int = 135) -> list[str]:
+    chunks, cur = [], ""
+    for sent in re.split(r"(?<=[;:,.!?])\s+|(?<=[；：，。！？])", text):
+        piece = sent + " " if sent and len(sent[-1].encode("utf-8")) == 1 else sent
+        if len(cur.encode("utf-8")) + len(sent.encode("utf-8")) <= max_chars:
+            cur += piece
+        else:
+            if cur:
+                chunks.append(cur.strip())
+            cur = piece
+    if cur:
+        chunks.append(cur.strip())
+    return chunks
+
+
+def convert_peft_state_dict_to_plain(state_dict: dict, lora_alpha: float = 32.0, lora_r: int = 16) -> dict:
+    """PEFT checkpoints (`base_model.model.*`, `.base_layer.`, `.lora_A/B.default.`) -> plain names with the low-rank
+    update merged: W <- W + (B @ A) * alpha / r."""
+    prefix = "base_model.model."
+    if not any(k.startswith(prefix) for k in state_dict):
+        return state_dict
+    scale = lora_alpha / lora_r
+    plain = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+    out = {}
+    for k, v in plain.items():
+        if ".lora_A." in k or ".lora_B." in k:
+            continue
+        if k.endswith(".base_layer.weight"):
+            stem = k[: -len(".base_layer.weight")]
+            a, b = plain.get(stem + ".lora_A.default.weight"), plain.get(stem + ".lora_B.default.weight")
+            if a is not None and b is not None:
+                out[stem + ".weight"] = (v + (b @ a).to(v.dtype) * scale).to(v.dtype)
+            else:
+                out[k] = v
+        elif k.endswith(".base_layer.bias"):
+            out.setdefault(k[: -len(".base_layer.bias")] + ".bias", v)
+        else:
+            out[k] = v
+    return out
+
+
+def load_checkpoint(model, ckpt_path: str, device: str, dtype=None, use_ema: bool = True):
+    """Loads a reference checkpoint into a CFM whose backbone is a HIP backbone.  `dtype` is accepted for signature
+    compatibility; the engine's operand precision is the backbone's `precision` (weights are kept in fp32 on the host
+    and converted when they are uploaded)."""
+    if ckpt_path.split(".")[-1] == "safetensors":
+        from safetensors.torch import load_file
+
+        ckpt = load_file(ckpt_path, device="cpu")
+        ckpt = {"ema_model_state_dict": ckpt} if use_ema else {"model_state_dict": ckpt}
+    else:
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+    if use_ema:
+        sd = {k.replace("ema_model.", ""): v for k, v in ckpt["ema_model_state_dict"].items() if k not in ("initted", "step")}
+        for legacy in ("mel_spec.mel_stft.mel_scale.fb", "mel_spec.mel_stft.spectrogram.window"):
+            sd.pop(legacy, None)
+    else:
+        sd = ckpt["model_state_dict"]
+    model.load_state_dict(convert_peft_state_dict_to_plain(sd))
+    return model.to(device)
+
+
+def load_model(model_cls, model_cfg: dict, ckpt_path: str | None, mel_spec_type=mel_spec_type, vocab_file: str = "",
+               ode_method=ode_method, use_ema=True, device="cuda", precision="bf16", **_ignored):
+    """CFM(transformer=model_cls(**model_cfg, text_num_embeds=vocab_size + 1, mel_dim=100), ...) + load_checkpoint.
+    `ckpt_path=None` keeps whatever weights the caller loads afterwards (e.g. init_synthetic())."""
+    vocab_char_map, vocab_size = load_vocab(vocab_file) if vocab_file else (None, 256)
+    tr = model_cls(**model_cfg, text_num_embeds=vocab_size + 1, mel_dim=n_mel_channels, precision=precision)
+    model = CFM(transformer=tr,
+                mel_spec_kwargs=dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length,
+                                     n_mel_channels=n_mel_channels, target_sample_rate=target_sample_rate,
+                                     mel_spec_type=mel_spec_type),
+                odeint_kwargs=dict(method=ode_method), vocab_char_map=vocab_char_map)
+    if ckpt_path:
+        model = load_checkpoint(model, ckpt_path, device, use_ema=use_ema)
+    return model.to(device)
+
+
+def load_vocoder(vocoder_name="vocos", is_local=True, local_path="", device="cuda", hf_cache_dir=None):
+    if vocoder_name != "vocos":
+        raise NotImplementedError("BigVGAN is an un-vendored submodule of the reference (no source): not built")
+    if not is_local:
+        raise RuntimeError("no network in this environment: pass is_local=True and a directory with pytorch_model.bin")
+    voc = Vocos()
+    sd = torch.load(f"{local_path}/pytorch_model.bin", map_location="cpu", weights_only=True)
+    voc.load_state_dict(sd)
+    return voc.eval().to(device)
+
+
+def prompt_numerics(audio: torch.Tensor, sr: int, ref_text: str, gen_text: str, speed_: float = speed,
+                    fix_duration_=None, target_rms_: float = target_rms):
+    """The host arithmetic of process_batch (utils_infer.py:523-533,541-544,678-685) factored out so that it can be
+    pinned by hand-computed cases: returns (audio mono RMS-normalised [1, nw], rms, ref_audio_len, duration)."""
+    if audio.shape[0] > 1:
+        audio = torch.mean(audio, dim=0, keepdim=True)
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < target_rms_:
+        audio = audio * target_rms_ / rms
+    if sr != target_sample_rate:
+        raise NotImplementedError("resampling needs torchaudio (absent): provide the prompt at 24 kHz")
+    if len(ref_text[-1].encode("utf-8")) == 1:
+        ref_text = ref_text + " "
+    local_speed = 0.3 if len(gen_text.encode("utf-8")) < 10 else speed_
+    ref_audio_len = audio.shape[-1] // hop_length
+    if fix_duration_ is not None:
+        duration = int(fix_duration_ * target_sample_rate / hop_length)
+    else:
+        ref_text_len = len(ref_text.encode("utf-8"))
+        gen_text_len = len(gen_text.encode("utf-8"))
+        duration = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / local_speed)
+    return audio, float(rms), ref_text, ref_audio_len, duration
+
+
+def cross_fade_concat(waves: list[np.ndarray], cross_fade_duration_: float = cross_fade_duration) -> np.ndarray:
+    """utils_infer.py:734-775."""
+    if cross_fade_duration_ <= 0:
+        return np.concatenate(waves)
+    final = waves[0]
+    for nxt in waves[1:]:
+        n = min(int(cross_fade_duration_ * target_sample_rate), len(final), len(nxt))
+        if n <= 0:
+            final = np.concatenate([final, nxt])
+            continue
+        mix = final[-n:] * np.linspace(1, 0, n) + nxt[:n] * np.linspace(0, 1, n)
+        final = np.concatenate([final[:-n], mix, nxt[n:]])
+    return final
+
+
+def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
+                        progress=None, target_rms=target_rms, cross_fade_duration=cross_fade_duration,
+                        nfe_step=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
+                        speed=speed, fix_duration=fix_duration, device=None, seed=None):
+    """Returns (final_wave f32 numpy, sample_rate, combined mel [100, T_total]) like the non-streaming branch."""
+    audio, sr = ref_audio
+    device = device if device is not None else model_obj.device
+    waves, specs = [], []
+    for gen_text in gen_text_batches:
+        a, rms, rtext, ref_len, duration = prompt_numerics(audio, sr, ref_text, gen_text, speed, fix_duration, target_rms)
+        a = a.to(device)
+        text_list = [rtext + gen_text]
+        with torch.inference_mode():
+            generated, _ = model_obj.sample(cond=a, text=text_list, duration=duration, steps=nfe_step,
+                                            cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, seed=seed)
+            generated = generated.to(torch.float32)[:, ref_len:, :].permute(0, 2, 1)
+            wave = vocoder.decode(generated)
+            if rms < target_rms:
+                wave = wave * rms / target_rms
+            waves.append(wave.squeeze().cpu().numpy())
+            specs.append(generated[0].cpu().numpy())
+    if not waves:
+        return None, target_sample_rate, None
+    return cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
+
+
+def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_type=mel_spec_type, target_rms=target_rms,
+                  cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
+                  sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, seed=None):
+    """ref_audio = (tensor [channels, nw], sample_rate) instead of a path (no torchaudio.load here); otherwise
+    utils_infer.py:453-498: max_chars from the prompt's bytes-per-second, chunk, infer_batch_process."""
+    audio, sr = ref_audio
+    max_chars = int(len(ref_text.encode("utf-8")) / (audio.shape[-1] / sr) * (22 - audio.shape[-1] / sr) * speed)
+    batches = chunk_text(gen_text, max_chars=max_chars)
+    return infer_batch_process((audio, sr), ref_text, batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
+                               target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
+                               cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed,
+                               fix_duration=fix_duration, device=device, seed=seed)

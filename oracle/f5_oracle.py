@@ -485,3 +485,31 @@ def vocos_decode(V, mel, n_fft=1024, hop=256):
     re, im = istft_head_spec(V, vocos_backbone(V, mel))
     spec = torch.complex(re, im)
     return torch.istft(spec, n_fft, hop, n_fft, window=torch.hann_window(n_fft), center=True)
+
+
+# ----------------------------------------------------------------------------------------- mel front-end
+
+
+def htk_mel_filterbank(n_freqs, n_mels, sample_rate, f_min=0.0, f_max=None):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale="htk") restated from its published definition
+    (torchaudio is absent from the container: PARITY UNPINNED)."""
+    f_max = float(sample_rate // 2) if f_max is None else f_max
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)  # [n_freqs, n_mels]
+
+
+def mel_spectrogram_vocos(wav, n_fft=1024, hop=256, n_mels=100, sample_rate=24000):
+    """modules.py:78-104: MelSpectrogram(power=1, center=True, norm=None) -> clamp(min=1e-5).log(); wav [b, nw] -> [b, n_mels, T]."""
+    spec = torch.stft(wav, n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+    fb = htk_mel_filterbank(n_fft // 2 + 1, n_mels, sample_rate)
+    mel = torch.matmul(spec.transpose(1, 2), fb).transpose(1, 2)
+    return mel.clamp(min=1e-5).log()

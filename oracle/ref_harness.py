@@ -102,7 +102,10 @@ def _odeint(fn, y0, t, method="euler", **kw):
 
 
 def _mod(name, **attrs):
+    import importlib.machinery
+
     m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
@@ -165,3 +168,33 @@ def build_reference_cfm(arch: dict, text_num_embeds: int, mel_dim: int = 100, ba
     tr = cls(**arch, text_num_embeds=text_num_embeds, mel_dim=mel_dim)
     model = ref.CFM(transformer=tr, mel_spec_module=InertMelSpec())
     return model.eval()
+
+
+def load_infer():
+    """Imports the reference's inference harness (src/f5_tts/infer/utils_infer.py) for pinning its host arithmetic
+    (chunk_text, _convert_peft_state_dict_to_plain, the duration formula / slicing / rescale / cross-fade of
+    infer_batch_process).  Additional inert stand-ins: matplotlib, pydub, vocos, and a pass-through `rjieba.cut`
+    (the default pinyin tokeniser then leaves ASCII text as a list of characters; tokenisers are out of scope and the
+    fake model used by the tests ignores token identity)."""
+    ref = load()
+    if getattr(ref, "infer", None) is not None:
+        return ref.infer
+    mpl = _mod("matplotlib", use=lambda *a, **k: None)
+    mpl.pylab = _mod("matplotlib.pylab")
+    _mod("pydub", AudioSegment=object, silence=types.SimpleNamespace())
+    _mod("vocos", Vocos=object)
+    if "transformers" not in sys.modules:  # only `pipeline` (Whisper ASR, out of scope) is imported from it
+        _mod("transformers", pipeline=None)
+    sys.modules["rjieba"].cut = lambda t: [t]
+    sys.modules["pypinyin"].lazy_pinyin = lambda seg, **k: list(seg)
+    sys.modules["pypinyin"].Style = types.SimpleNamespace(TONE3=0)
+    model_pkg = sys.modules["f5_tts.model"]
+    model_pkg.CFM = ref.CFM
+    for pkg, rel in (("f5_tts.infer", "f5_tts/infer"), ("f5_tts.train", "f5_tts/train"),
+                     ("f5_tts.train.datasets", "f5_tts/train/datasets")):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF_SRC, rel)]
+            sys.modules[pkg] = m
+    ref.infer = importlib.import_module("f5_tts.infer.utils_infer")
+    return ref.infer

@@ -149,3 +149,29 @@ def test_vocos_decode_vs_oracle():
         e = (wav - ref).abs().max().item()
         print(f"[vocos f32] T={T}: wav Linf {e:.3e} (peak {ref.abs().max().item():.3f})")
         assert e < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_mel_frontend_vs_oracle_and_wav_prompt():
+    """wav -> log-mel (modules.py:78-146) on the HIP path vs the torch.stft restatement; then sample() with a raw-wave
+    prompt (cfm.py:106-109) equals sample() with that mel."""
+    g = torch.Generator().manual_seed(11)
+    for nw in (24000, 12345):
+        wav = torch.randn(2, nw, generator=g) * 0.1
+        ref = O.mel_spectrogram_vocos(wav)
+        ms = P.mel.MelSpec()
+        got = ms(wav.to(DEV)).cpu()
+        assert got.shape == ref.shape == (2, 100, nw // 256 + 1)
+        e = (got - ref).abs().max().item()
+        print(f"[mel front-end] nw={nw}: log-mel Linf {e:.3e}")
+        assert e < 2e-3
+    meta, a = load_golden("sample_b1_nfe16")
+    sd = synthetic_weights(meta)
+    tr = P.DiT(**meta["arch"], text_num_embeds=meta["nvocab"], mel_dim=100, precision="f32")
+    tr.load_state_dict(sd)
+    model = P.CFM(transformer=tr).to(DEV)
+    wav = (torch.randn(1, 24 * 256 - 1, generator=g) * 0.1).to(DEV)   # -> 24 mel frames
+    mel = model.mel_spec(wav).permute(0, 2, 1)
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1)
+    o1, _ = model.sample(wav, a["text"], 64, **kw)
+    o2, _ = model.sample(mel, a["text"], 64, **kw)
+    assert torch.equal(o1, o2)
