@@ -175,3 +175,33 @@ def test_mel_frontend_vs_oracle_and_wav_prompt():
     o1, _ = model.sample(wav, a["text"], 64, **kw)
     o2, _ = model.sample(mel, a["text"], 64, **kw)
     assert torch.equal(o1, o2)
+
+
+def test_infer_process_end_to_end_vs_oracle():
+    """wav prompt + text -> wav through the harness (infer.py) on the HIP path (mel front-end, sample(), Vocos) against
+    the same pipeline assembled from oracle pieces on the CPU."""
+    from f5_tts_amd import infer as I
+
+    arch = P.config.F5TTS_TINY
+    g = torch.Generator().manual_seed(5)
+    tr = P.DiT(**arch, text_num_embeds=257, mel_dim=100, precision="f32").init_synthetic(seed=2)
+    model = P.CFM(transformer=tr).to(DEV)          # no vocab map -> utf-8 byte tokens (cfm.py:119-123)
+    vsd = P.weights.synthetic_state_dict(P.weights.vocos_param_shapes(P.config.VOCOS_TINY), seed=4)
+    voc = P.Vocos(P.config.VOCOS_TINY)
+    voc.load_state_dict(vsd)
+    voc.to(DEV)
+    audio = torch.randn(1, 9000, generator=g) * 0.05
+    ref_text, gen_text = "hello there.", "General Kenobi, you are a bold one."
+    kw = dict(nfe_step=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    wave, sr, spec = I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw)
+    # oracle pipeline
+    a, rms, rtext, ref_len, dur = I.prompt_numerics(audio, 24000, ref_text, gen_text)
+    cond = O.mel_spectrogram_vocos(a).permute(0, 2, 1)
+    text = P.utils.list_str_to_tensor([rtext + gen_text])
+    out, _ = O.sample(tr.state_dict(), arch, cond, text, dur, steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    wref = O.vocos_decode(vsd, out[:, ref_len:].permute(0, 2, 1)) * (rms / 0.1 if rms < 0.1 else 1.0)
+    assert sr == 24000 and wave.shape == (wref.shape[-1],)
+    e_mel = float((torch.from_numpy(spec) - out[0, ref_len:].t()).abs().max())
+    e_wav = float((torch.from_numpy(wave) - wref[0]).abs().max())
+    print(f"[harness e2e f32] mel Linf {e_mel:.3e}, wav Linf {e_wav:.3e}")
+    assert e_mel < 1e-3 and e_wav < 1e-3
