@@ -119,20 +119,40 @@ struct Prof {
 };
 enum { PC_GEMM = 0, PC_ATTN = 1, PC_LN = 2, PC_CONV = 3, PC_MISC = 4, PC_TEXT = 5, PC_TIME = 6 };
 
-// Host staging (pinned) for small per-call scalars: time grid, lengths.
+// Host staging (pinned) for small per-call scalars (time grid, lengths): a ring of slots, each guarded by an event
+// recorded after its last async copy, so that consecutive calls never synchronise the stream.
 struct Staging {
-    char* host = nullptr;
-    size_t cap = 0;
+    enum { NSLOT = 8 };
+    char* host[NSLOT] = {};
+    size_t cap[NSLOT] = {};
+    hipEvent_t ev[NSLOT] = {};
+    bool used[NSLOT] = {};
+    int next = 0;
     ~Staging() {
-        if (host) (void)hipHostFree(host);
+        for (int i = 0; i < NSLOT; ++i) {
+            if (host[i]) (void)hipHostFree(host[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
     }
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return F5_OK;
-        if (host) (void)hipHostFree(host);
-        host = nullptr;
-        cap = 0;
-        HIPCHK(hipHostMalloc((void**)&host, bytes, hipHostMallocDefault));
-        cap = bytes;
+    int acquire(size_t bytes, char** out, int* slot) {
+        const int i = next;
+        next = (next + 1) % NSLOT;
+        if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        if (used[i]) HIPCHK(hipEventSynchronize(ev[i]));  // the copies issued from this slot NSLOT calls ago are done
+        if (bytes > cap[i]) {
+            if (host[i]) (void)hipHostFree(host[i]);
+            host[i] = nullptr;
+            cap[i] = 0;
+            HIPCHK(hipHostMalloc((void**)&host[i], std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+            cap[i] = std::max<size_t>(bytes, 4096);
+        }
+        *out = host[i];
+        *slot = i;
+        return F5_OK;
+    }
+    int release(int slot, hipStream_t s) {
+        HIPCHK(hipEventRecord(ev[slot], s));
+        used[slot] = true;
         return F5_OK;
     }
 };
@@ -183,8 +203,14 @@ struct f5_engine {
     Staging stage;
     Prof prof;
     int res_B = 0, res_N = 0, res_S = 0;
+    // The unconditional text embedding (all filler tokens) depends only on the weights and the length: cache it across
+    // sample() calls for the single-utterance case (the reference recomputes it every call, dit.py:244-269).
+    float* uc_buf = nullptr;
+    size_t uc_cap = 0;
+    int uc_N = -1;
     ~f5_engine() {
         for (void* p : owned) (void)hipFree(p);
+        if (uc_buf) (void)hipFree(uc_buf);
     }
 };
 
@@ -229,6 +255,7 @@ extern "C" int f5_load_weight(f5_engine* e, const char* name, const void* dev, c
                               f5_stream stream) {
     if (!e) return fail(F5_EINVAL, "null engine");
     e->finalized = false;
+    e->uc_N = -1;
     return e->ws.put(name, dev, shape, ndim, (hipStream_t)stream);
 }
 
@@ -785,11 +812,11 @@ template <typename T>
 static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, const int32_t* lens_host, int B,
                         hipStream_t s) {
     const size_t bytes = (size_t)nT * 4 + (size_t)2 * B * 4 + 64;
-    // the staging buffer may still be read by an earlier async copy on this stream
-    HIPCHK(hipStreamSynchronize(s));
-    CHK(e->stage.ensure(bytes));
-    float* th = reinterpret_cast<float*>(e->stage.host);
-    int* lh = reinterpret_cast<int*>(e->stage.host + (size_t)nT * 4);
+    char* hb = nullptr;
+    int slot = 0;
+    CHK(e->stage.acquire(bytes, &hb, &slot));
+    float* th = reinterpret_cast<float*>(hb);
+    int* lh = reinterpret_cast<int*>(hb + (size_t)nT * 4);
     if (nT > 0) {
         memcpy(th, t_host, (size_t)nT * 4);
         HIPCHK(hipMemcpyAsync(w.tdev, th, (size_t)nT * 4, hipMemcpyHostToDevice, s));
@@ -799,7 +826,7 @@ static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, c
         for (int i = 0; i < B; ++i) lh[i] = lh[B + i] = lens_host[i] + add;
         HIPCHK(hipMemcpyAsync(w.lens, lh, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
     }
-    return F5_OK;
+    return e->stage.release(slot, s);
 }
 
 static int check_ready(f5_engine* e, int B, int N) {
@@ -891,7 +918,26 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
     const int* tlens = c.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
     CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
-    if (use_cfg) CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
+    if (use_cfg) {
+        const size_t ucn = (size_t)N * c.text_dim;
+        if (B == 1 && !lens_host && e->uc_N == N && e->uc_buf) {
+            HIPCHK(hipMemcpyAsync(w.text_u, e->uc_buf, ucn * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else {
+            CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
+            if (B == 1 && !lens_host) {
+                if (ucn > e->uc_cap) {
+                    HIPCHK(hipStreamSynchronize(s));
+                    if (e->uc_buf) (void)hipFree(e->uc_buf);
+                    e->uc_buf = nullptr;
+                    e->uc_cap = 0;
+                    HIPCHK(hipMalloc((void**)&e->uc_buf, ucn * sizeof(float)));
+                    e->uc_cap = ucn;
+                }
+                HIPCHK(hipMemcpyAsync(e->uc_buf, w.text_u, ucn * sizeof(float), hipMemcpyDeviceToDevice, s));
+                e->uc_N = N;
+            }
+        }
+    }
     float* y = out;  // ODE state lives in the caller's output buffer
     if (y != y0) HIPCHK(hipMemcpyAsync(y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (traj) HIPCHK(hipMemcpyAsync(traj, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -12,6 +12,7 @@ enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8 };
 
 inline int pick_cfg_v2(int M, int N) {
     auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (M <= 64) return G2_64x64_4W;  // skinny (time MLP, AdaLN stack over the NFE steps): weight-streaming, no row reuse to gain
     if (tiles(128, 128) >= 240) return G2_128x128_8W;
     if (tiles(128, 64) >= 200) return G2_128x64_8W;
     return G2_64x64_4W;
