@@ -22,28 +22,63 @@ namespace f5 {
 
 // One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
 // key-padding mask costs nothing on interior tiles.
+// single-instruction helpers: fmaxf() on MFMA results makes hipcc emit a canonicalising v_max per operand, and
+// __shfl_xor lowers to ds_bpermute (an LDS round trip); these keep the softmax at one VALU op per step
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max over the 4 lane groups (lanes l, l^16, l^32, l^48) with the gfx950 half/row swaps instead of LDS permutes
+__device__ __forceinline__ float group_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // a[0]: lanes 32-63 now hold lanes 0-31's value ...
+    float m = vmax3(v, __builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, m);
+    auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return vmax3(m, __builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+
+// One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
+// key-padding mask costs nothing on interior tiles.  All eight fragment reads of the tile (4 K, 4 V^T) are issued
+// up front as asm ds_reads with hand-counted lgkmcnt waits (gemm2.h explains why).
 template <int STAGE_IDX, bool EDGE>
-__device__ __forceinline__ void attn2_tile(const char* __restrict__ smem, int k_off, int kc0, int kc1, int v_off, int vc,
+__device__ __forceinline__ void attn2_tile(unsigned lds_base, int k_off, int kc0, int kc1, int v_off, int vc,
                                            const u32x4 (&qf)[2][2], f32x4 (&o)[4][2], float (&mrun)[2], float (&lrun)[2],
                                            int key_base, int kv_len) {
     constexpr int TILE = 64 * 128;
     constexpr float L2E = 1.4426950408889634f;
-    const char* sb = smem + STAGE_IDX * (2 * TILE);
+    const unsigned sb = lds_base + STAGE_IDX * (2 * TILE);
+    u32x4 kf[2][2], vf[4];   // kf[f][ks]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) lds_read_b128_asm(kf[f][ks], sb + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) lds_read_b128_asm(vf[dt], sb + v_off + dt * 16 * 128 + vc);
     // ---- S^T (this wave's 32 keys x 32 queries); MFMA row i = 4a + b of sub-tile ks holds key 8a + 4ks + b
     f32x4 s[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<6>(kf[0][0], kf[0][1]);
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const u32x4 kf = *reinterpret_cast<const u32x4*>(sb + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[0][ks], qf[qs][0], s[ks][qs]);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<4>(kf[1][0], kf[1][1]);
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf, qf[qs][f], s[ks][qs]);
-        }
-    }
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[1][ks], qf[qs][1], s[ks][qs]);
     // ---- online softmax over this wave's keys (lane group g owns keys key_base + 4 ks + r)
     float alpha[2];
     bool grew = false;
@@ -56,11 +91,10 @@ __device__ __forceinline__ void attn2_tile(const char* __restrict__ smem, int k_
                 for (int r = 0; r < 4; ++r)
                     if (key_base + ks * 4 + r >= kv_len) s[ks][qs][r] = -1e30f;
         }
-        float mloc = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
-                           fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(mrun[qs], mloc);
+        float mloc = vmax3(vmax3(s[0][qs][0], s[0][qs][1], s[0][qs][2]), vmax3(s[0][qs][3], s[1][qs][0], s[1][qs][1]),
+                           vmax2(s[1][qs][2], s[1][qs][3]));
+        mloc = group_max(mloc);
+        const float mnew = vmax2(mrun[qs], mloc);
         grew = grew || (mnew > mrun[qs]);
         alpha[qs] = __builtin_amdgcn_exp2f((mrun[qs] - mnew) * L2E);
         mrun[qs] = mnew;
@@ -93,11 +127,12 @@ __device__ __forceinline__ void attn2_tile(const char* __restrict__ smem, int k_
                      (bf16_t)s[1][qs][0], (bf16_t)s[1][qs][1], (bf16_t)s[1][qs][2], (bf16_t)s[1][qs][3]};
         pf2[qs] = __builtin_bit_cast(u32x4, pv);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_lgkm<0>(vf[0], vf[1], vf[2], vf[3]);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        const u32x4 vf = *reinterpret_cast<const u32x4*>(sb + v_off + dt * 16 * 128 + vc);
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<bf16_t>::run(vf, pf2[qs], o[dt][qs]);
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<bf16_t>::run(vf[dt], pf2[qs], o[dt][qs]);
     }
 }
 
@@ -172,9 +207,11 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
     const int v_off = TILE + l15 * 128;
     const int vc = ((4 * kh + g) ^ (l15 & 7)) * 16;       // keys 32 kh + 8 g .. + 7 of dh row dt*16 + l15
     const int key_lane = kh * 32 + 8 * g;                 // first key (inside the tile) owned by this lane group
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     issue(0, 0);
     issue(1, 1);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // nothing but the tile loop's own LDS reads on the lgkm counter
     const int nfull = kv_len / 64;                        // tiles without masked keys
     int kt = 0;
 #define F5_ATTN_STEP(SI, EDGE_)                                                                                        \
@@ -182,7 +219,7 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
         wait_vmcnt<(NS - 2) * L>();                                                                                    \
         __builtin_amdgcn_s_barrier();                                                                                  \
         issue(kt + NS - 1, (SI + NS - 1) % NS);                                                                        \
-        attn2_tile<SI, EDGE_>(smem, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
+        attn2_tile<SI, EDGE_>(lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
         ++kt;                                                                                                          \
     }
     while (kt + 3 <= nfull) {
