@@ -22,59 +22,58 @@ namespace f5 {
 
 // One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
 // key-padding mask costs nothing on interior tiles.
-// single-instruction helpers: fmaxf() on MFMA results makes hipcc emit a canonicalising v_max per operand, and
-// __shfl_xor lowers to ds_bpermute (an LDS round trip); these keep the softmax at one VALU op per step
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vmax2(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 // max over the 4 lane groups (lanes l, l^16, l^32, l^48) with the gfx950 half/row swaps instead of LDS permutes
 __device__ __forceinline__ float group_max(float v) {
     const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // a[0]: lanes 32-63 now hold lanes 0-31's value ...
-    float m = vmax3(v, __builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {own | partner l^32} in some order per half
+    float m = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
     const unsigned w = __builtin_bit_cast(unsigned, m);
-    auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);
-    return vmax3(m, __builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);   // {own | partner l^16}
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
 }
 
 // One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
 // key-padding mask costs nothing on interior tiles.  All eight fragment reads of the tile (4 K, 4 V^T) are issued
 // up front as asm ds_reads with hand-counted lgkmcnt waits (gemm2.h explains why).
-template <int STAGE_IDX, bool EDGE>
-__device__ __forceinline__ void attn2_tile(unsigned lds_base, int k_off, int kc0, int kc1, int v_off, int vc,
+template <int STAGE_IDX, bool EDGE, int VAR>
+__device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_base, int k_off, int kc0, int kc1, int v_off, int vc,
                                            const u32x4 (&qf)[2][2], f32x4 (&o)[4][2], float (&mrun)[2], float (&lrun)[2],
                                            int key_base, int kv_len) {
     constexpr int TILE = 64 * 128;
     constexpr float L2E = 1.4426950408889634f;
     const unsigned sb = lds_base + STAGE_IDX * (2 * TILE);
     u32x4 kf[2][2], vf[4];   // kf[f][ks]
+    const char* sbp = smem_ptr + STAGE_IDX * (2 * TILE);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) lds_read_b128_asm(kf[f][ks], sb + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+        for (int ks = 0; ks < 2; ++ks) {
+            if (VAR & 1) lds_read_b128_asm(kf[f][ks], sb + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+            else kf[f][ks] = *reinterpret_cast<const u32x4*>(sbp + k_off + ks * 4 * 128 + (f ? kc1 : kc0));
+        }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) lds_read_b128_asm(vf[dt], sb + v_off + dt * 16 * 128 + vc);
+    for (int dt = 0; dt < 4; ++dt) {
+        if (VAR & 1) lds_read_b128_asm(vf[dt], sb + v_off + dt * 16 * 128 + vc);
+        else vf[dt] = *reinterpret_cast<const u32x4*>(sbp + v_off + dt * 16 * 128 + vc);
+    }
     // ---- S^T (this wave's 32 keys x 32 queries); MFMA row i = 4a + b of sub-tile ks holds key 8a + 4ks + b
     f32x4 s[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<6>(kf[0][0], kf[0][1]);
+    if (VAR & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<6>(kf[0][0], kf[0][1]);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[0][ks], qf[qs][0], s[ks][qs]);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<4>(kf[1][0], kf[1][1]);
+    if (VAR & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<4>(kf[1][0], kf[1][1]);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -91,20 +90,31 @@ __device__ __forceinline__ void attn2_tile(unsigned lds_base, int k_off, int kc0
                 for (int r = 0; r < 4; ++r)
                     if (key_base + ks * 4 + r >= kv_len) s[ks][qs][r] = -1e30f;
         }
-        float mloc = vmax3(vmax3(s[0][qs][0], s[0][qs][1], s[0][qs][2]), vmax3(s[0][qs][3], s[1][qs][0], s[1][qs][1]),
-                           vmax2(s[1][qs][2], s[1][qs][3]));
-        mloc = group_max(mloc);
-        const float mnew = vmax2(mrun[qs], mloc);
+        // scores in log2 units first: the products are compiler-visible VALU results (hipcc pads the MFMA -> VALU
+        // wait states itself and knows they are canonical, so fmaxf() needs no extra canonicalising v_max and fuses
+        // into v_max3).  NEVER feed MFMA accumulators to inline-asm VALU: nothing pads that hazard (stale reads).
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[ks][qs][r] *= L2E;
+        float mloc = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
+                           fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
+        if (VAR & 2) {
+            mloc = group_max(mloc);
+        } else {
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        }
+        const float mnew = fmaxf(mrun[qs], mloc);
         grew = grew || (mnew > mrun[qs]);
-        alpha[qs] = __builtin_amdgcn_exp2f((mrun[qs] - mnew) * L2E);
+        alpha[qs] = __builtin_amdgcn_exp2f(mrun[qs] - mnew);   // running max kept in log2 units
         mrun[qs] = mnew;
-        const float mb = mnew * L2E;
         float psum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[ks][qs][r] * L2E - mb);
+                float p = __builtin_amdgcn_exp2f(s[ks][qs][r] - mnew);
                 if (EDGE && key_base + ks * 4 + r >= kv_len) p = 0.f;
                 s[ks][qs][r] = p;
                 psum += p;
@@ -127,8 +137,10 @@ __device__ __forceinline__ void attn2_tile(unsigned lds_base, int k_off, int kc0
                      (bf16_t)s[1][qs][0], (bf16_t)s[1][qs][1], (bf16_t)s[1][qs][2], (bf16_t)s[1][qs][3]};
         pf2[qs] = __builtin_bit_cast(u32x4, pv);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    wait_lgkm<0>(vf[0], vf[1], vf[2], vf[3]);
+    if (VAR & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm<0>(vf[0], vf[1], vf[2], vf[3]);
+    }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
@@ -140,7 +152,8 @@ __device__ __forceinline__ void attn2_tile(unsigned lds_base, int k_off, int kc0
 // rows {8a + 4ks + b}; kswz makes those land on 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int kswz(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }
 
-static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int VAR>
+__global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int H,
                                                                int N, int Npad, const int* __restrict__ kv_lens,
                                                                int nbatch_lens) {
@@ -211,7 +224,7 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
 
     issue(0, 0);
     issue(1, 1);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                   // nothing but the tile loop's own LDS reads on the lgkm counter
+    if (VAR & 1) __builtin_amdgcn_s_waitcnt(0xC07F);      // nothing but the tile loop's own LDS reads on the lgkm counter
     const int nfull = kv_len / 64;                        // tiles without masked keys
     int kt = 0;
 #define F5_ATTN_STEP(SI, EDGE_)                                                                                        \
@@ -219,7 +232,7 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
         wait_vmcnt<(NS - 2) * L>();                                                                                    \
         __builtin_amdgcn_s_barrier();                                                                                  \
         issue(kt + NS - 1, (SI + NS - 1) % NS);                                                                        \
-        attn2_tile<SI, EDGE_>(lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
+        attn2_tile<SI, EDGE_, VAR>(smem, lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
         ++kt;                                                                                                          \
     }
     while (kt + 3 <= nfull) {
@@ -262,7 +275,7 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
         for (int qs = 0; qs < 2; ++qs) {
             const float m1 = mb[(32 + qs) * 64 + lane], l1 = mb[(34 + qs) * 64 + lane];
             const float m = fmaxf(mrun[qs], m1);
-            const float a0 = exp2f((mrun[qs] - m) * L2E), a1 = exp2f((m1 - m) * L2E);
+            const float a0 = exp2f(mrun[qs] - m), a1 = exp2f(m1 - m);   // maxima are kept in log2 units
             const float inv = 1.0f / (lrun[qs] * a0 + l1 * a1);
             const int q = q0 + qs * 16 + l15;
             if (q < N) {
@@ -280,18 +293,29 @@ static __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __r
     }
 }
 
+// diagnostic switch (bit 0: asm LDS reads + counted waits, bit 1: asm max3 / permlane swaps)
+inline int& attn2_variant() { static int v = 3; return v; }
 inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp, int H,
                                     int N, int Npad, const int* kv_lens, int nbatch_lens) {
     constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     dim3 grid(Bp * H, (N + 127) / 128);
-    hipLaunchKernelGGL(attn2_fwd_kernel, grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens);
+    const int var = attn2_variant();
+#define F5_ATTN2_LAUNCH(V)                                                                                             \
+    {                                                                                                                  \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<V>),                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);                      \
+            if (e != hipSuccess) return e;                                                                             \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        hipLaunchKernelGGL(attn2_fwd_kernel<V>, grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens); \
+    }
+    if (var == 0) F5_ATTN2_LAUNCH(0)
+    else if (var == 1) F5_ATTN2_LAUNCH(1)
+    else if (var == 2) F5_ATTN2_LAUNCH(2)
+    else F5_ATTN2_LAUNCH(3)
+#undef F5_ATTN2_LAUNCH
     return hipGetLastError();
 }
 

@@ -266,6 +266,7 @@ static int gemm2_impl(const float* A, const float* W, const float* bias, int act
 
 // experimental entry (not in the public header): v2 GEMM with config id; optional timing over `iters` launches
 extern "C" int f5x_set_xcd_mode(int32_t on) { xcd_mode() = on; return 0; }
+extern "C" int f5x_set_attn_variant(int32_t v) { attn2_variant() = v; return 0; }
 extern "C" int f5x_set_cold_weights(int32_t on) { g_cold_weights = on; return 0; }
 extern "C" int f5x_set_out_bf16(int32_t on) { g_out_bf16 = on; return 0; }
 extern "C" int f5x_gemm2(int32_t prec, const float* A, const float* W, const float* bias, int32_t act, float* out, int32_t M,

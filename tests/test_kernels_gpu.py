@@ -124,3 +124,26 @@ def test_layernorm_modulate(D):
     ref = F.layer_norm(x, (D,), eps=1e-6) * (1 + sc.repeat_interleave(rpb, 0)) + sh.repeat_interleave(rpb, 0)
     out = k_layernorm_mod(x, sc, sh, rpb)
     assert (out - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_kernels_are_bitwise_deterministic(prec):
+    """Race detector: a stale LDS / register read shows up as run-to-run differences long before it breaks a tolerance
+    (an inline-asm VALU consumer of MFMA accumulators did exactly that: nothing pads that hazard)."""
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(2, 8, 1024, 64, generator=g).to(DEV) for _ in range(3))
+    ref = k_attention(prec, q, k, v)
+    for _ in range(6):
+        assert torch.equal(k_attention(prec, q, k, v), ref)
+    A = torch.randn(2048, 1024, generator=g).to(DEV)
+    W = (torch.randn(1024, 1024, generator=g) / 32).to(DEV)
+    for tile in ((0, 0), (-2, 0), (-8, 0), (-9, 0)):
+        ref = k_gemm(prec, A, W, None, tile=tile)
+        for _ in range(4):
+            assert torch.equal(k_gemm(prec, A, W, None, tile=tile), ref)
+    x = torch.randn(2, 300, 1024, generator=g).to(DEV)
+    w = (torch.randn(1024, 64, 31, generator=g) * 0.02).to(DEV)
+    b = torch.randn(1024, generator=g).to(DEV)
+    ref = k_convpos(prec, x, w, b, x)
+    for _ in range(4):
+        assert torch.equal(k_convpos(prec, x, w, b, x), ref)
