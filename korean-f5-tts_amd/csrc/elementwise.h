@@ -150,8 +150,10 @@ static __global__ void strip_first_token_kernel(const float* __restrict__ in, fl
 // ------------------------------------------------------------------------------------- CFG + Euler update
 // y += dt * (p + (p - u) * cfg)   (cfm.py:190-191 + fixed-grid Euler, f5_tts_trtllm.py:360-369); also emits the new
 // state into the trajectory slot.  pred holds [cond half ; uncond half] when cfg is on.
-static __global__ void euler_cfg_kernel(float* __restrict__ y, const float* __restrict__ pred, long half_elems, float dt,
-                                 float cfg, int use_cfg, float* __restrict__ traj_slot) {
+static __global__ void euler_cfg_kernel(float* __restrict__ y, const float* __restrict__ pred, long half_elems,
+                                        const float* __restrict__ tgrid, int step, float cfg, int use_cfg,
+                                        float* __restrict__ traj_slot) {
+    const float dt = tgrid[step + 1] - tgrid[step];   // f32 subtraction, as torch does on the f32 grid (cfm.py:211-218)
     const long n4 = half_elems / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 yy = reinterpret_cast<float4*>(y)[i];

@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -208,7 +210,25 @@ struct f5_engine {
     float* uc_buf = nullptr;
     size_t uc_cap = 0;
     int uc_N = -1;
+    // HIP graphs of whole sample() bodies (one per problem signature): ~2600 launches per utterance become one
+    // hipGraphLaunch, so the host (shared, sometimes slow) can never be the bottleneck of the ODE loop.
+    struct GraphEntry { std::string key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    std::vector<std::string> warm;      // signatures (without cache state) that have run eagerly once
+    hipStream_t cap_stream = nullptr;
+    int graphs_on = -1;                 // -1: read F5_HIP_GRAPH from the environment on first use
+    int res_nt = 0;
+    void clear_graphs() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+        warm.clear();
+    }
     ~f5_engine() {
+        clear_graphs();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (void* p : owned) (void)hipFree(p);
         if (uc_buf) (void)hipFree(uc_buf);
     }
@@ -256,6 +276,7 @@ extern "C" int f5_load_weight(f5_engine* e, const char* name, const void* dev, c
     if (!e) return fail(F5_EINVAL, "null engine");
     e->finalized = false;
     e->uc_N = -1;
+    e->clear_graphs();
     return e->ws.put(name, dev, shape, ndim, (hipStream_t)stream);
 }
 
@@ -436,6 +457,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
 extern "C" int f5_finalize(f5_engine* e, f5_stream stream) {
     if (!e) return fail(F5_EINVAL, "null engine");
     hipStream_t s = (hipStream_t)stream;
+    e->clear_graphs();
     for (void* p : e->owned) (void)hipFree(p);
     e->owned.clear();
     e->pf = Packed<float>();
@@ -467,10 +489,15 @@ template <typename T> struct Work {
     T* cat2;         // UNetT concat buffer [rows, 2D]
     float* skips;    // UNetT skip stack
     float* pred_all; // UNetT proj_out over N+1 tokens
+    // sample(): engine-owned copies of the call's inputs / outputs so that the captured graph has stable pointers
+    float *in_cond, *y, *out_buf, *traj_buf;
+    unsigned char* in_mask;
+    long long* in_text;
     int Npad;
 };
 
 template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Work<T>& w, int B, int N, int S) {
+    const size_t NT = (size_t)std::max(e->res_nt, 1);
     const f5_config& c = e->cfg;
     a.reset();
     const size_t Bp = 2 * (size_t)B, D = c.dim, Dt = c.text_dim, F = c.ff_dim, mel = c.mel_dim;
@@ -503,6 +530,12 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.ao = a.take<T>(rows * e->inner);
     w.vt = a.take<T>(Bp * c.heads * 64 * w.Npad);
     w.ffh = a.take<T>(rows * F);
+    w.in_cond = a.take<float>((size_t)B * N * mel);
+    w.y = a.take<float>((size_t)B * N * mel);
+    w.out_buf = a.take<float>((size_t)B * N * mel);
+    w.traj_buf = a.take<float>((size_t)(S + 1) * B * N * mel);
+    w.in_mask = a.take<unsigned char>((size_t)B * N + 16);
+    w.in_text = a.take<long long>((size_t)B * NT + 2);
     w.cat2 = nullptr;
     w.skips = nullptr;
     w.pred_all = nullptr;
@@ -535,6 +568,7 @@ static int ensure_arena(f5_engine* e, int B, int N, int S) {
         HIPCHK(hipMalloc((void**)&e->arena.base, need_b));
         HIPCHK(hipMemset(e->arena.base, 0, need_b));  // padded K / V^T regions must never hold NaN bit patterns
         e->arena.cap = need_b;
+        e->clear_graphs();                            // captured pointers are stale
     }
     e->res_B = B; e->res_N = N; e->res_S = S;
     return F5_OK;
@@ -895,24 +929,21 @@ extern "C" int f5_dit_forward(f5_engine* e, const float* x, const float* cond, c
                : forward_impl<float>(e, x, cond, text, nt, time_host, lens_host, B, N, cfg_infer, drop_audio_cond, drop_text, out, s);
 }
 
+// the stream-ordered body of sample(): everything between "inputs are in the arena" and "outputs are in the arena"
 template <typename T>
-static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
-                       int nt, const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N,
-                       float* out, float* traj, hipStream_t s) {
+static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_strength, bool has_lens, int B, int N,
+                       bool want_traj, hipStream_t s) {
     const f5_config& c = e->cfg;
     const int mel = c.mel_dim;
     const bool use_cfg = !(cfg_strength < 1e-5f);
     const int Bp = use_cfg ? 2 * B : B;
-    CHK(ensure_arena(e, B, N, steps));
-    Work<T> w;
-    carve<T>(e, w, e->res_B, e->res_N, e->res_S);
-    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s));
-    const int* lens_dev = lens_host ? w.lens : nullptr;
+    const int* lens_dev = has_lens ? w.lens : nullptr;
     const long half = (long)B * N * mel;
+    const int64_t* text = reinterpret_cast<const int64_t*>(w.in_text);
     // step_cond = where(cond_mask, cond, 0)   (cfm.py:151-153)
     e->prof.begin(PC_MISC, s);
-    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, cond, (const float*)nullptr,
-                       cond_mask, w.step_cond, (long)B * N, mel);
+    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.in_cond, (const float*)nullptr,
+                       w.in_mask, w.step_cond, (long)B * N, mel);
     KCHK();
     e->prof.end(s);
     CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
@@ -920,11 +951,11 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
     if (use_cfg) {
         const size_t ucn = (size_t)N * c.text_dim;
-        if (B == 1 && !lens_host && e->uc_N == N && e->uc_buf) {
+        if (B == 1 && !has_lens && e->uc_N == N && e->uc_buf) {
             HIPCHK(hipMemcpyAsync(w.text_u, e->uc_buf, ucn * sizeof(float), hipMemcpyDeviceToDevice, s));
         } else {
             CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
-            if (B == 1 && !lens_host) {
+            if (B == 1 && !has_lens) {   // (never reached under capture: a cache miss always runs eagerly)
                 if (ucn > e->uc_cap) {
                     HIPCHK(hipStreamSynchronize(s));
                     if (e->uc_buf) (void)hipFree(e->uc_buf);
@@ -938,24 +969,104 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
             }
         }
     }
-    float* y = out;  // ODE state lives in the caller's output buffer
-    if (y != y0) HIPCHK(hipMemcpyAsync(y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (traj) HIPCHK(hipMemcpyAsync(traj, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (want_traj) HIPCHK(hipMemcpyAsync(w.traj_buf, w.y, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int i = 0; i < steps; ++i) {
-        CHK(run_backbone<T>(e, w, y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s));
-        const float dt = t_host[i + 1] - t_host[i];
+        CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s));
         e->prof.begin(PC_MISC, s);
-        hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, y, w.pred, half, dt, cfg_strength,
-                           use_cfg ? 1 : 0, traj ? traj + (size_t)(i + 1) * half : nullptr);
+        hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.y, w.pred, half, w.tdev, i,
+                           cfg_strength, use_cfg ? 1 : 0, want_traj ? w.traj_buf + (size_t)(i + 1) * half : nullptr);
         KCHK();
         e->prof.end(s);
     }
     // out = where(cond_mask, cond, y)   (cfm.py:221-223)
     e->prof.begin(PC_MISC, s);
-    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, cond, (const float*)y, cond_mask, out,
-                       (long)B * N, mel);
+    hipLaunchKernelGGL(select_rows_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.in_cond, (const float*)w.y, w.in_mask,
+                       w.out_buf, (long)B * N, mel);
     KCHK();
     e->prof.end(s);
+    return F5_OK;
+}
+
+static bool graphs_enabled(f5_engine* e) {
+    if (e->graphs_on < 0) {
+        const char* v = getenv("F5_HIP_GRAPH");
+        e->graphs_on = (v && v[0] == '0') ? 0 : 1;
+    }
+    return e->graphs_on == 1;
+}
+
+template <typename T>
+static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
+                       int nt, const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N,
+                       float* out, float* traj, hipStream_t s) {
+    const int mel = e->cfg.mel_dim;
+    const long half = (long)B * N * mel;
+    if (nt > e->res_nt) {   // the text staging buffer is part of the arena plan
+        e->res_nt = nt;
+        e->clear_graphs();
+    }
+    CHK(ensure_arena(e, B, N, steps));
+    Work<T> w;
+    carve<T>(e, w, e->res_B, e->res_N, e->res_S);
+    // ---- inputs -> arena (eager, on the caller's stream)
+    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s));
+    HIPCHK(hipMemcpyAsync(w.in_cond, cond, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(w.y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(w.in_mask, cond_mask, (size_t)B * N, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(w.in_text, text, (size_t)B * nt * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    // ---- body: replay a captured graph when this signature has been seen, else run eagerly (and remember it)
+    const bool use_cfg = !(cfg_strength < 1e-5f);
+    const bool uc_hit = use_cfg && B == 1 && !lens_host && e->uc_N == N && e->uc_buf;
+    const bool uc_store = use_cfg && B == 1 && !lens_host && !uc_hit;
+    unsigned cfg_bits;
+    memcpy(&cfg_bits, &cfg_strength, 4);
+    char kb[160];
+    snprintf(kb, sizeof(kb), "%d|%d|%d|%d|%08x|%d|%d", B, N, nt, steps, cfg_bits, lens_host ? 1 : 0, traj ? 1 : 0);
+    const std::string base_key(kb);
+    const std::string key = base_key + (uc_hit ? "|uc" : "|nouc");
+    bool done = false;
+    if (graphs_enabled(e) && !e->prof.on && !uc_store) {
+        for (auto& g : e->graphs)
+            if (g.key == key) {
+                HIPCHK(hipGraphLaunch(g.exec, s));
+                done = true;
+                break;
+            }
+        const bool is_warm = std::find(e->warm.begin(), e->warm.end(), base_key) != e->warm.end();
+        if (!done && is_warm) {
+            if (!e->cap_stream) HIPCHK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                const int rc = sample_body<T>(e, w, nt, steps, cfg_strength, lens_host != nullptr, B, N, traj != nullptr, e->cap_stream);
+                const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+                if (rc == F5_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    if (e->graphs.size() >= 16) {
+                        (void)hipGraphExecDestroy(e->graphs.front().exec);
+                        (void)hipGraphDestroy(e->graphs.front().graph);
+                        e->graphs.erase(e->graphs.begin());
+                    }
+                    e->graphs.push_back({key, graph, exec});
+                    HIPCHK(hipGraphLaunch(exec, s));
+                    done = true;
+                } else {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();   // capture is an optimisation: fall back to eager launches
+                    e->graphs_on = 0;
+                }
+            } else {
+                (void)hipGetLastError();
+                e->graphs_on = 0;
+            }
+        }
+    }
+    if (!done) {
+        CHK(sample_body<T>(e, w, nt, steps, cfg_strength, lens_host != nullptr, B, N, traj != nullptr, s));
+        if (std::find(e->warm.begin(), e->warm.end(), base_key) == e->warm.end()) e->warm.push_back(base_key);
+    }
+    // ---- outputs -> caller
+    HIPCHK(hipMemcpyAsync(out, w.out_buf, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (traj) HIPCHK(hipMemcpyAsync(traj, w.traj_buf, (size_t)(steps + 1) * half * sizeof(float), hipMemcpyDeviceToDevice, s));
     return F5_OK;
 }
 
