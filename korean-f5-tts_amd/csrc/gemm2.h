@@ -29,18 +29,42 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_dst) {
 __device__ __forceinline__ void lds_read_b128_asm(u32x4& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
-template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+// (the lgkmcnt field is 4 bits: a larger allowance is clamped to 15, which only waits a little longer)
+template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N > 15 ? 15 : N)); }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N > 15 ? 15 : N));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c) {
-    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N > 15 ? 15 : N));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N > 15 ? 15 : N));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
-    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N > 15 ? 15 : N));
+}
+
+// wait for the fragments MFMA row i of half kk needs (issue order per kk: a[0], w[0..NJ-1], a[1..MI-1])
+template <int R, int MI, int NJ, int KK, int I>
+__device__ __forceinline__ void wait_row_ct(u32x4 (&af)[2][MI], u32x4 (&wf)[2][NJ]) {
+    constexpr int idx = KK * (MI + NJ) + NJ + I;
+    constexpr int allow = R - 1 - idx;
+    if constexpr (I == 0) {
+        if constexpr (NJ == 1) wait_lgkm<allow>(af[KK][0], wf[KK][0]);
+        else if constexpr (NJ == 2) wait_lgkm<allow>(af[KK][0], wf[KK][0], wf[KK][1]);
+        else if constexpr (NJ == 3) wait_lgkm<allow>(af[KK][0], wf[KK][0], wf[KK][1], wf[KK][2]);
+        else wait_lgkm<allow>(af[KK][0], wf[KK][0], wf[KK][1], wf[KK][2], wf[KK][3]);
+    } else {
+        wait_lgkm<allow>(af[KK][I]);
+    }
+}
+template <int R, int MI, int NJ>
+__device__ __forceinline__ void wait_row(int kk, int i, u32x4 (&af)[2][MI], u32x4 (&wf)[2][NJ]) {
+    // kk and i are compile-time constants after unrolling; the switch folds away
+#define F5_WR(KK, I) if (kk == KK && i == I) { if constexpr (I < MI) wait_row_ct<R, MI, NJ, KK, I>(af, wf); }
+    F5_WR(0, 0) F5_WR(0, 1) F5_WR(0, 2) F5_WR(0, 3) F5_WR(0, 4) F5_WR(0, 5) F5_WR(0, 6) F5_WR(0, 7)
+    F5_WR(1, 0) F5_WR(1, 1) F5_WR(1, 2) F5_WR(1, 3) F5_WR(1, 4) F5_WR(1, 5) F5_WR(1, 6) F5_WR(1, 7)
+#undef F5_WR
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
@@ -156,25 +180,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     __builtin_amdgcn_sched_barrier(0);  // keep the previous row's MFMAs above this wait
-                    // outstanding reads allowed when row i of kk starts
-                    if (kk == 0) {
-                        if (i == 0) { if constexpr (NJ == 2) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1]);
-                                      else if constexpr (NJ == 3) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1], wf[0][2]);
-                                      else if constexpr (NJ == 4) wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0], wf[0][1], wf[0][2], wf[0][3]);
-                                      else wait_lgkm<R - 1 - (NJ + 0)>(af[0][0], wf[0][0]); }
-                        else if (i == 1) wait_lgkm<(R - 1 - (NJ + 1)) < 0 ? 0 : (R - 1 - (NJ + 1))>(af[0][i]);
-                        else if (i == 2) wait_lgkm<(R - 1 - (NJ + 2)) < 0 ? 0 : (R - 1 - (NJ + 2))>(af[0][i]);
-                        else wait_lgkm<(R - 1 - (NJ + 3)) < 0 ? 0 : (R - 1 - (NJ + 3))>(af[0][i]);
-                    } else {
-                        constexpr int B0 = MI + NJ;
-                        if (i == 0) { if constexpr (NJ == 2) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1]);
-                                      else if constexpr (NJ == 3) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1], wf[1][2]);
-                                      else if constexpr (NJ == 4) wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0], wf[1][1], wf[1][2], wf[1][3]);
-                                      else wait_lgkm<R - 1 - (B0 + NJ + 0)>(af[1][0], wf[1][0]); }
-                        else if (i == 1) wait_lgkm<(R - 1 - (B0 + NJ + 1)) < 0 ? 0 : (R - 1 - (B0 + NJ + 1))>(af[1][i]);
-                        else if (i == 2) wait_lgkm<(R - 1 - (B0 + NJ + 2)) < 0 ? 0 : (R - 1 - (B0 + NJ + 2))>(af[1][i]);
-                        else wait_lgkm<(R - 1 - (B0 + NJ + 3)) < 0 ? 0 : (R - 1 - (B0 + NJ + 3))>(af[1][i]);
-                    }
+                    // outstanding reads allowed when row i of kk starts = R - 1 - (index of the last read it needs)
+                    wait_row<R, MI, NJ>(kk, i, af, wf);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (!trj[j]) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);

@@ -200,11 +200,9 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         case 10: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 11: return launch_gemm2_cfg<T, 128, 128, 2, 4, 5, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 12: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 13: return launch_gemm2_cfg<T, 128, 192, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 14: return launch_gemm2_cfg<T, 128, 96, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 15: return launch_gemm2_cfg<T, 64, 192, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 110: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
-        case 210: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 13: return launch_gemm2_cfg<T, 256, 256, 2, 4, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 14: return launch_gemm2_cfg<T, 256, 128, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 15: return launch_gemm2_cfg<T, 256, 128, 2, 4, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         // diagnostic floors of config 2 / 6 / 8 (outputs are garbage): 1xx = DMA only, 2xx = compute only
         case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
         case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
