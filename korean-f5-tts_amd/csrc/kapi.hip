@@ -274,3 +274,56 @@ extern "C" int f5x_gemm2(int32_t prec, const float* A, const float* W, const flo
     return prec == F5_PREC_BF16 ? gemm2_impl<bf16_t>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s)
                                 : gemm2_impl<float>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s);
 }
+
+
+// diagnostic: what a boundary between DIFFERENT kernels costs.  Repeating patterns, cold (rotating) weights:
+//   LN alone, GEMM alone, [LN -> GEMM] (real producer/consumer edge), [LN' -> GEMM] (no data edge),
+//   [GEMM a -> GEMM b] (two instantiations), [GEMM a -> GEMM a]
+extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32_t iters, float* res6, f5_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    typedef bf16_t T;
+    Scratch<float> x, sc;
+    Scratch<T> xn, xn2, w, o;
+    const int ncopy = 48;
+    HIPCHK(x.alloc((size_t)M * K));
+    HIPCHK(sc.alloc((size_t)2 * K));
+    HIPCHK(xn.alloc((size_t)M * K));
+    HIPCHK(xn2.alloc((size_t)M * K));
+    HIPCHK(w.alloc((size_t)ncopy * N * K));
+    HIPCHK(o.alloc((size_t)M * N));
+    HIPCHK(hipMemsetAsync(x.p, 0x3c, (size_t)M * K * 4, s));
+    HIPCHK(hipMemsetAsync(sc.p, 0, (size_t)2 * K * 4, s));
+    HIPCHK(hipMemsetAsync(w.p, 0x3c, (size_t)ncopy * N * K * 2, s));
+    auto ln = [&](T* dst) {
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, x.p, K, dst, K, M, K, 1e-6f, sc.p, sc.p + K, 0, M, 1);
+    };
+    auto gm = [&](int i, int c) -> hipError_t {
+        return gemm2_dispatch<T>(c, s, xn.p, K, w.p + (size_t)(i % ncopy) * N * K, K, M, N, K, EpiStore<T>{o.p, N, nullptr, F5_ACT_GELU_TANH});
+    };
+    const int cfg_b = cfg == 2 ? 7 : 2;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 8; ++i) { ln(xn.p); HIPCHK(gm(i, cfg)); HIPCHK(gm(i, cfg_b)); }
+    for (int mode = 0; mode < 6; ++mode) {
+        HIPCHK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) {
+            switch (mode) {
+                case 0: ln(xn.p); break;
+                case 1: HIPCHK(gm(i, cfg)); break;
+                case 2: ln(xn.p); HIPCHK(gm(i, cfg)); break;
+                case 3: ln(xn2.p); HIPCHK(gm(i, cfg)); break;
+                case 4: HIPCHK(gm(i, cfg)); HIPCHK(gm(i + 7, cfg_b)); break;
+                default: HIPCHK(gm(i, cfg)); HIPCHK(gm(i + 7, cfg)); break;
+            }
+        }
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        res6[mode] = ms * 1000.f / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return F5_OK;
+}
