@@ -30,9 +30,12 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float mish(float x) {
-    // x * tanh(softplus(x)); torch softplus threshold 20
-    float sp = x > 20.0f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    // x * tanh(softplus(x)), torch softplus threshold 20.  With n = e^x: tanh(log(1 + n)) = ((1+n)^2 - 1) / ((1+n)^2 + 1)
+    // = t / (t + 2), t = n (n + 2) -- no cancellation for either sign of x, one exp and one rcp instead of the
+    // log1pf + tanhf expansions (which made every kernel that inlines it ~1 KB larger per element)
+    const float n = expf(fminf(x, 20.0f));
+    const float t = n * (n + 2.0f);
+    return x > 20.0f ? x : x * t * __frcp_rn(t + 2.0f);
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {

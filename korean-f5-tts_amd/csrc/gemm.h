@@ -16,6 +16,7 @@
 // double buffering (global loads for tile t+1 are issued before the MFMAs of tile t and written to the other LDS
 // buffer after them; one barrier per K tile).
 #pragma once
+#include <type_traits>
 #include "f5_common.h"
 
 namespace f5 {
@@ -49,7 +50,12 @@ template <> struct Mma<float> {
 //   void   tstore(TRowCtx, TColCtx, v)                 -- only reached if tile_transposed() can be true
 struct NoCtx {};
 
-template <typename TO> struct EpiStore {  // out = act(acc + bias)
+// ACT >= 0 fixes the activation at compile time.  This matters more than it looks: with a run-time `act` every one of
+// the 32 stores of a lane inlines all six activations and the kernel grows to 63 KB (128x128) -- the whole 64 KB
+// instruction cache a CU pair shares -- so every launch that follows a different kernel starts instruction-cold
+// (+7 us measured per launch, tools/pair_time.py).  Host code builds EpiStore<TO> (ACT = -1, run-time field) and the
+// launchers rewrite it to the static form through with_static_act().
+template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     TO* out; int ldo; const float* bias; int act;
     struct RowCtx { TO* p; };
     struct ColCtx { float4 b; int n; };
@@ -61,13 +67,28 @@ template <typename TO> struct EpiStore {  // out = act(acc + bias)
         return {bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0), n};
     }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v) const {
-        store4(r.p + c.n, apply_act(v[0] + c.b.x, act), apply_act(v[1] + c.b.y, act), apply_act(v[2] + c.b.z, act),
-               apply_act(v[3] + c.b.w, act));
+        const int a = ACT >= 0 ? ACT : act;
+        store4(r.p + c.n, apply_act(v[0] + c.b.x, a), apply_act(v[1] + c.b.y, a), apply_act(v[2] + c.b.z, a),
+               apply_act(v[3] + c.b.w, a));
     }
     __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
     __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
     __device__ __forceinline__ void tstore(const NoCtx&, const NoCtx&, f32x4) const {}
 };
+
+// f(epilogue-with-static-activation); any other epilogue type passes through unchanged
+template <typename Epi, typename F> inline hipError_t with_static_act(const Epi& e, F&& f) { return f(e); }
+template <typename TO, typename F> inline hipError_t with_static_act(const EpiStore<TO, -1>& e, F&& f) {
+    switch (e.act) {
+        case F5_ACT_NONE: return f(EpiStore<TO, F5_ACT_NONE>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_GELU_TANH: return f(EpiStore<TO, F5_ACT_GELU_TANH>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_GELU_ERF: return f(EpiStore<TO, F5_ACT_GELU_ERF>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_SILU: return f(EpiStore<TO, F5_ACT_SILU>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_MISH: return f(EpiStore<TO, F5_ACT_MISH>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_LOGCLAMP: return f(EpiStore<TO, F5_ACT_LOGCLAMP>{e.out, e.ldo, e.bias, e.act});
+        default: return hipErrorInvalidValue;
+    }
+}
 
 // x[m][n] = res[m][n] + gate[b(m)][n] * (acc + bias)    (res may alias x; gate == nullptr -> 1; rows m with
 // (m % rows_per_batch) >= lens[m / rows_per_batch] are left as res: the reference's masked_fill(~mask, 0) on the
@@ -284,8 +305,8 @@ inline GemmTile pick_tile(int M, int N) {
 }
 
 template <typename T, int BM, int BN, typename Epi>
-inline hipError_t launch_gemm_tile(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                   const Epi& epi) {
+inline hipError_t launch_gemm_tile_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                       const Epi& epi) {
     constexpr int smem = 2 * (BM + BN) * GEMM_ROW_STRIDE;
     static bool attr_set = false;
     if (!attr_set) {
@@ -297,6 +318,14 @@ inline hipError_t launch_gemm_tile(hipStream_t s, const T* A, int lda, const T* 
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm_tn_kernel<T, BM, BN, Epi>), grid, dim3(256), smem, s, A, lda, W, ldw, M, N, K, epi);
     return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, typename Epi>
+inline hipError_t launch_gemm_tile(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                   const Epi& epi) {
+    return with_static_act(epi, [&](const auto& e) {
+        return launch_gemm_tile_raw<T, BM, BN, std::decay_t<decltype(e)>>(s, A, lda, W, ldw, M, N, K, e);
+    });
 }
 
 // A: [M, K] (lda elements), W: [N, K] (ldw elements); K, lda, ldw multiples of 16/sizeof(T); N multiple of 4.

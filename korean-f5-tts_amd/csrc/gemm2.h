@@ -68,10 +68,8 @@ __device__ __forceinline__ void wait_row(int kk, int i, u32x4 (&af)[2][MI], u32x
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
-                                                                   const T* __restrict__ W, int ldw, int M, int N, int K,
-                                                                   Epi epi, int xa, int xb) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restrict__ A, int lda, const T* __restrict__ W,
+                                                  int ldw, int M, int N, int K, const Epi& epi, int xa, int xb) {
     constexpr int NW = WM * WN;
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
     constexpr int EPC = 16 / sizeof(T);
@@ -228,6 +226,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __re
     }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
+                                                                   const T* __restrict__ W, int ldw, int M, int N, int K,
+                                                                   Epi epi, int xa, int xb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_tn_glds_body<T, BM, BN, WM, WN, NS, Epi, MODE>(smem, A, lda, W, ldw, M, N, K, epi, xa, xb);
+}
+
 // chooses (xa, xb): tiles_m % xa == 0, tiles_n % xb == 0 and the number of rectangles a multiple of 8; prefers the most
 // square rectangle with xa * xb close to one XCD's share of a full wave of workgroups (32 CUs).  (0, 0) = keep order.
 inline int& xcd_mode() { static int m = 1; return m; }
@@ -252,7 +258,7 @@ inline void pick_xcd_rect(int tiles_m, int tiles_n, int* xa, int* xb) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
-inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                    const Epi& epi) {
     constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
     static bool attr_set = false;
@@ -269,6 +275,14 @@ inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* 
     hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
                        ldw, M, N, K, epi, xa, xb);
     return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
+inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
+                                   const Epi& epi) {
+    return with_static_act(epi, [&](const auto& e) {
+        return launch_gemm2_raw<T, BM, BN, WM, WN, NS, std::decay_t<decltype(e)>, MODE>(s, A, lda, W, ldw, M, N, K, e);
+    });
 }
 
 }  // namespace f5

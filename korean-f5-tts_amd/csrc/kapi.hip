@@ -188,28 +188,15 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
                                  const Epi& epi) {
     switch (cfg) {
         case 0: return launch_gemm2_cfg<T, 128, 128, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 1: return launch_gemm2_cfg<T, 128, 128, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 2: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 3: return launch_gemm2_cfg<T, 128, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 4: return launch_gemm2_cfg<T, 128, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 5: return launch_gemm2_cfg<T, 64, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 6: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 7: return launch_gemm2_cfg<T, 128, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 8: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 9: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 10: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 11: return launch_gemm2_cfg<T, 128, 128, 2, 4, 5, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 12: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 13: return launch_gemm2_cfg<T, 256, 256, 2, 4, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 14: return launch_gemm2_cfg<T, 256, 128, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        case 15: return launch_gemm2_cfg<T, 256, 128, 2, 4, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-        // diagnostic floors of config 2 / 6 / 8 (outputs are garbage): 1xx = DMA only, 2xx = compute only
+        // diagnostic floors of config 2 (outputs are garbage): 1xx = DMA only, 2xx = compute only
         case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
         case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
-        case 106: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
-        case 206: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
-        case 108: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
-        case 208: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
         default: return hipErrorInvalidValue;
     }
 }
@@ -305,10 +292,29 @@ extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     for (int i = 0; i < 8; ++i) { ln(xn.p); HIPCHK(gm(i, cfg)); HIPCHK(gm(i, cfg_b)); }
-    for (int mode = 0; mode < 6; ++mode) {
+    // modes 6, 7 (N == 3 * 16 * 64 only): the same GEMM with the fused QKV epilogue / with EpiStore + bias, both alone
+    Scratch<T> q3;
+    Scratch<float> tab;
+    const bool qkv_ok = N == 3072 && M % 1024 == 0;
+    HIPCHK(q3.alloc((size_t)3 * M * 1024 + 4096));
+    HIPCHK(tab.alloc((size_t)2 * 4096 * 32 + N));
+    HIPCHK(hipMemsetAsync(tab.p, 0, ((size_t)2 * 4096 * 32 + N) * 4, s));
+    auto gq = [&](int i) -> hipError_t {
+        EpiQKV<T> e{q3.p, q3.p + (size_t)M * 1024, q3.p + (size_t)2 * M * 1024, tab.p + 2 * 4096 * 32, tab.p, tab.p + 4096 * 32,
+                    1024, 1024, 16, 1, 0.125f};
+        return gemm2_dispatch<T>(cfg, s, xn.p, K, w.p + (size_t)(i % ncopy) * N * K, K, M, N, K, e);
+    };
+    auto gb = [&](int i) -> hipError_t {
+        return gemm2_dispatch<T>(cfg, s, xn.p, K, w.p + (size_t)(i % ncopy) * N * K, K, M, N, K,
+                                 EpiStore<T>{q3.p, N, tab.p + 2 * 4096 * 32, F5_ACT_NONE});
+    };
+    for (int mode = 0; mode < 8; ++mode) {
+        if (mode >= 6 && !qkv_ok) { res6[mode] = 0.f; continue; }
         HIPCHK(hipEventRecord(e0, s));
         for (int i = 0; i < iters; ++i) {
             switch (mode) {
+                case 6: HIPCHK(gq(i)); break;
+                case 7: HIPCHK(gb(i)); break;
                 case 0: ln(xn.p); break;
                 case 1: HIPCHK(gm(i, cfg)); break;
                 case 2: ln(xn.p); HIPCHK(gm(i, cfg)); break;
