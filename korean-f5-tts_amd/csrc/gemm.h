@@ -61,6 +61,7 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     struct ColCtx { float4 b; int n; };
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
+    static constexpr bool kTransposes = false;
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const { return {out + (size_t)m * ldo}; }
     __device__ __forceinline__ ColCtx col(int n) const {
@@ -100,6 +101,7 @@ struct EpiGateRes {
     struct ColCtx { float4 b; int n; };
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
+    static constexpr bool kTransposes = false;
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / rows_per_batch;
@@ -134,6 +136,7 @@ template <typename TO> struct EpiQKV {
     struct ColCtx { float4 b; TO* dst; size_t hoff; int d; bool rot; float scale; };
     struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
     struct TColCtx { float b; size_t hoff; };
+    static constexpr bool kTransposes = true;
     __device__ __forceinline__ bool tile_transposed(int n0) const { return n0 >= 2 * H * 64; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / Nseq, pos = m - b * Nseq;

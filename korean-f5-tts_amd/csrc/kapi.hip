@@ -299,9 +299,13 @@ extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32
     HIPCHK(q3.alloc((size_t)3 * M * 1024 + 4096));
     HIPCHK(tab.alloc((size_t)2 * 4096 * 32 + N));
     HIPCHK(hipMemsetAsync(tab.p, 0, ((size_t)2 * 4096 * 32 + N) * 4, s));
+    static int variant = getenv("F5X_QKV_VARIANT") ? atoi(getenv("F5X_QKV_VARIANT")) : 0;
     auto gq = [&](int i) -> hipError_t {
         EpiQKV<T> e{q3.p, q3.p + (size_t)M * 1024, q3.p + (size_t)2 * M * 1024, tab.p + 2 * 4096 * 32, tab.p, tab.p + 4096 * 32,
                     1024, 1024, 16, 1, 0.125f};
+        if (variant == 1) { e.H = 24; e.k = q3.p + (size_t)M * 1536; }  // no transposed third: q | k of 24 heads each
+        if (variant == 2) e.pe_heads = 0;                                 // no rotary
+        if (variant == 3) { e.H = 24; e.k = q3.p + (size_t)M * 1536; e.Nseq = 1; e.Npad = 1; }  // same code, row-major q | k
         return gemm2_dispatch<T>(cfg, s, xn.p, K, w.p + (size_t)(i % ncopy) * N * K, K, M, N, K, e);
     };
     auto gb = [&](int i) -> hipError_t {
