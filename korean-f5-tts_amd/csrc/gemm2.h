@@ -152,8 +152,13 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     __builtin_amdgcn_s_waitcnt(0xC07F);
     // The K loop exists once per orientation: a run-time orientation test inside it compiles to a pair of taken
     // branches around every MFMA (measured +11 us on the 2048x3072x1024 QKV projection).
+    // Tried on top of this loop and dropped (tools/gemm2_sweep.py, M = 2048, cold weights): (a) staggering waves 4-7
+    // half a block behind waves 0-3 so that SIMD partners alternate LDS reads and MFMAs: 13.8 -> 15.5 us on FF1;
+    // (b) a second fragment set so that block kt reads tile kt+1 while it multiplies tile kt: +-2 % everywhere.
+    // Neither the LDS read burst nor the MFMA issue bounds these shapes: the L2 -> LDS fill does (MODE 1).
     auto kloop = [&](auto trc) {
         constexpr bool TR = decltype(trc)::value;
+        constexpr int R = 2 * (MI + NJ);
         int stage = 0;
         for (int kt = 0; kt < nkt; ++kt) {
             if (MODE != 2) wait_vmcnt<(NS - 2) * L>();  // this wave's pieces of tile kt have landed ...
@@ -161,12 +166,11 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
             int pf = stage + NS - 1;
             if (pf >= NS) pf -= NS;
             if (MODE != 2) issue(kt + NS - 1, pf);
-            const char* sb = smem + stage * STAGE;
             if (MODE != 1) {
                 // all fragment reads of the K-tile are issued first, in the order the MFMAs consume them:
                 //   per kk: a[0], w[0..NJ-1], a[1..MI-1];  the MFMA row i of kk may start once read (kk*(MI+NJ) + NJ + i) is back
                 u32x4 af[2][MI], wf[2][NJ];
-                const unsigned sbu = (unsigned)(size_t)(sb - smem) + lds_base;
+                const unsigned sbu = (unsigned)(stage * STAGE) + lds_base;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     const unsigned co = kk ? c1 : c0;
@@ -176,7 +180,6 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
                     for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
                 }
-                constexpr int R = 2 * (MI + NJ);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
