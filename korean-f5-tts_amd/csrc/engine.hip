@@ -1106,12 +1106,15 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
                     HIPCHK(hipGraphLaunch(exec, s));
                     done = true;
                 } else {
+                    // capture is an optimisation: fall back to eager launches, but say so (the wall time doubles on a busy host)
+                    fprintf(stderr, "libf5hip: HIP graph capture of sample() failed (body rc %d, end-capture: %s, last: %s); "
+                                    "continuing with eager launches\n", rc, hipGetErrorString(ce), hipGetErrorString(hipGetLastError()));
                     if (graph) (void)hipGraphDestroy(graph);
-                    (void)hipGetLastError();   // capture is an optimisation: fall back to eager launches
                     e->graphs_on = 0;
                 }
             } else {
-                (void)hipGetLastError();
+                fprintf(stderr, "libf5hip: hipStreamBeginCapture failed (%s); continuing with eager launches\n",
+                        hipGetErrorString(hipGetLastError()));
                 e->graphs_on = 0;
             }
         }

@@ -12,6 +12,10 @@
 #pragma once
 #include "gemm.h"
 
+#ifndef F5_GEMM_SPREAD_DMA
+#define F5_GEMM_SPREAD_DMA 0  // measured: out 9.1 -> 9.5 us, ff2 15.1 -> 16.4 us (tools/gemm2_sweep.py): off
+#endif
+
 namespace f5 {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -99,13 +103,17 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nkt = K / KT;
-    // orientation per 16-column sub-tile of this wave (wave-uniform): lets a block tile straddle the q|k -> v boundary
-    // (block tiles of 64/128/256 columns never straddle it: one flag for the whole block keeps the MFMA loop branch-free)
-    constexpr bool PERJ = (BN % 64) != 0 || BN == 192;
+    // Orientation per 16-column sub-tile of this wave (wave-uniform).  The transposed columns are a suffix of the output
+    // (EpiQKV: the V third), so within a wave they are the LAST nt of its NJ sub-tiles: nt is 0 or NJ except in the one
+    // wave of a block tile that straddles the boundary (only tiles whose width does not divide 64 * heads can: BN = 192).
     bool trj[NJ];
-    const bool tr_block = epi.tile_transposed(n0);
+    int nt = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) trj[j] = PERJ ? epi.tile_transposed(n0 + (wave % WN) * TN + j * 16) : tr_block;
+    for (int j = 0; j < NJ; ++j) {
+        trj[j] = Epi::kTransposes && epi.tile_transposed(n0 + (wave % WN) * TN + j * 16);
+        nt += trj[j] ? 1 : 0;
+    }
+    nt = __builtin_amdgcn_readfirstlane(nt);
 
     // per-lane source pointers for this wave's pieces (row inside the 8-row group = lane >> 3, swizzled chunk)
     const int lr = lane >> 3, lc = (lane & 7) ^ lr;
@@ -121,13 +129,15 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         const int row = min(n0 + (wave + i * NW) * 8 + lr, N - 1);
         wsrc[i] = W + (size_t)row * ldw + lc * EPC;
     }
+    auto issue_piece = [&](int p, int koff, char* base) {  // p is a compile-time constant after unrolling
+        if (p < LA) glds16(asrc[p] + koff, base + (wave + p * NW) * 1024);
+        else glds16(wsrc[p - LA] + koff, base + BM * GEMM_ROW_BYTES + (wave + (p - LA) * NW) * 1024);
+    };
     auto issue = [&](int kt, int stage) {
         char* base = smem + stage * STAGE;
         const int koff = min(kt, nkt - 1) * KT;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) glds16(asrc[i] + koff, base + (wave + i * NW) * 1024);
-#pragma unroll
-        for (int i = 0; i < LW; ++i) glds16(wsrc[i] + koff, base + BM * GEMM_ROW_BYTES + (wave + i * NW) * 1024);
+        for (int p = 0; p < L; ++p) issue_piece(p, koff, base);
     };
 
     f32x4 acc[MI][NJ];
@@ -150,14 +160,14 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // retire every scalar/LDS operation of the prologue: with nothing of another kind pending on the lgkm counter the
     // compiler can use counted lgkmcnt(N) waits (in-order LDS returns) inside the loop instead of lgkmcnt(0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    // The K loop exists once per orientation: a run-time orientation test inside it compiles to a pair of taken
+    // The K loop exists once per orientation pattern: a run-time orientation test inside it compiles to a pair of taken
     // branches around every MFMA (measured +11 us on the 2048x3072x1024 QKV projection).
     // Tried on top of this loop and dropped (tools/gemm2_sweep.py, M = 2048, cold weights): (a) staggering waves 4-7
     // half a block behind waves 0-3 so that SIMD partners alternate LDS reads and MFMAs: 13.8 -> 15.5 us on FF1;
     // (b) a second fragment set so that block kt reads tile kt+1 while it multiplies tile kt: +-2 % everywhere.
     // Neither the LDS read burst nor the MFMA issue bounds these shapes: the L2 -> LDS fill does (MODE 1).
-    auto kloop = [&](auto trc) {
-        constexpr bool TR = decltype(trc)::value;
+    auto kloop = [&](auto ntc) {
+        constexpr int NT = decltype(ntc)::value;  // number of trailing transposed sub-tiles (compile-time per loop copy)
         constexpr int R = 2 * (MI + NJ);
         int stage = 0;
         for (int kt = 0; kt < nkt; ++kt) {
@@ -165,7 +175,12 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
             __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
             int pf = stage + NS - 1;
             if (pf >= NS) pf -= NS;
-            if (MODE != 2) issue(kt + NS - 1, pf);
+            // An LDS-DMA piece costs its wave 100-185 issue cycles at the head of a block (MI355X_MICROARCH.md price list)
+            // and 25-60 in the gaps of the MFMA stream: the L pieces of tile kt+NS-1 are spread over the MFMA rows.
+            constexpr bool SPREAD = F5_GEMM_SPREAD_DMA && MODE == 0;
+            char* pbase = smem + pf * STAGE;
+            const int pkoff = min(kt + NS - 1, nkt - 1) * KT;
+            if (MODE != 2 && !SPREAD) issue(kt + NS - 1, pf);
             if (MODE != 1) {
                 // all fragment reads of the K-tile are issued first, in the order the MFMAs consume them:
                 //   per kk: a[0], w[0..NJ-1], a[1..MI-1];  the MFMA row i of kk may start once read (kk*(MI+NJ) + NJ + i) is back
@@ -189,9 +204,17 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
                         wait_row<R, MI, NJ>(kk, i, af, wf);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const bool trv = PERJ ? trj[j] : TR;  // TR is a compile-time constant: no branch in this loop
-                            if (!trv) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);
+                            if (j < NJ - NT) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);
                             else acc[i][j] = Mma<T>::run(af[kk][i], wf[kk][j], acc[i][j]);
+                        }
+                        if (SPREAD) {
+                            constexpr int NR = 2 * MI;
+#pragma unroll
+                            for (int p = 0; p < L; ++p)
+                                if (p * NR / L == kk * MI + i) {
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    issue_piece(p, pkoff, pbase);
+                                }
                         }
                     }
                 }
@@ -199,11 +222,19 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
             stage = stage + 1 == NS ? 0 : stage + 1;
         }
     };
-    if constexpr (Epi::kTransposes && !PERJ) {
-        if (tr_block) kloop(std::true_type{});
-        else kloop(std::false_type{});
+    if constexpr (Epi::kTransposes) {
+        constexpr bool MIXED = (BN % 64) != 0 || BN == 192;  // block tiles of 64/128/256 columns never straddle the boundary
+        if (nt == 0) kloop(std::integral_constant<int, 0>{});
+        else if (nt == NJ) kloop(std::integral_constant<int, NJ>{});
+        else if constexpr (MIXED && NJ >= 2) {
+            if (nt == 1) kloop(std::integral_constant<int, 1>{});
+            else if constexpr (NJ >= 3) {
+                if (nt == 2) kloop(std::integral_constant<int, 2>{});
+                else if constexpr (NJ >= 4) kloop(std::integral_constant<int, 3>{});
+            }
+        }
     } else {
-        kloop(std::false_type{});
+        kloop(std::integral_constant<int, 0>{});
     }
     wait_vmcnt<0>();  // drain the dummy tail loads before the block's LDS can be reallocated
 

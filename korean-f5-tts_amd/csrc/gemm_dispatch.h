@@ -8,20 +8,32 @@
 
 namespace f5 {
 
-enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8 };
+enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10 };
 
+// cost = rounds of workgroups over the 256 CUs x the time of one tile of that shape (us at K = 1024, measured with
+// tools/gemm2_sweep.py on a full chip: the per-K-step time grows much more slowly than the tile area, so the largest
+// tile that does not add a round wins; e.g. the QKV projection 2048 x 3072: 128x128 = 384 tiles = 2 rounds (25 us),
+// 128x192 = 256 tiles = 1 round (20 us)).
 inline int pick_cfg_v2(int M, int N) {
-    auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (M <= 64) return G2_64x64_4W;  // skinny (time MLP, AdaLN stack over the NFE steps): weight-streaming, no row reuse to gain
-    if (tiles(128, 128) >= 240) return G2_128x128_8W;
-    if (tiles(128, 64) >= 200) return G2_128x64_8W;
-    return G2_64x64_4W;
+    struct Cand { int id, bm, bn; float t; };
+    static const Cand cands[] = {{G2_128x192_8W, 128, 192, 19.3f}, {G2_128x128_8W, 128, 128, 14.5f},
+                                 {G2_128x64_8W, 128, 64, 7.3f}, {G2_64x64_4W, 64, 64, 4.0f}};
+    int best = G2_64x64_4W;
+    float best_cost = 3.0e38f;
+    for (const Cand& c : cands) {
+        const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        const float cost = (float)((tiles + 255) / 256) * c.t;
+        if (cost < best_cost) { best_cost = cost; best = c.id; }  // ties keep the larger tile (listed first)
+    }
+    return best;
 }
 
 template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                  const Epi& epi, int cfg) {
     switch (cfg) {
+        case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);

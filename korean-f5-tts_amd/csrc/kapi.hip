@@ -194,6 +194,8 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         case 7: return launch_gemm2_cfg<T, 128, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 8: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 9: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 10: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 11: return launch_gemm2_cfg<T, 128, 192, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         // diagnostic floors of config 2 (outputs are garbage): 1xx = DMA only, 2xx = compute only
         case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
         case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
