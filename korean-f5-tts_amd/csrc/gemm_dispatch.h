@@ -8,7 +8,7 @@
 
 namespace f5 {
 
-enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10 };
+enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10, G2_256x128_8W = 13 };
 
 // cost = rounds of workgroups over the 256 CUs x the time of one tile of that shape (us at K = 1024, measured with
 // tools/gemm2_sweep.py on a full chip: the per-K-step time grows much more slowly than the tile area, so the largest
@@ -17,7 +17,8 @@ enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_
 inline int pick_cfg_v2(int M, int N) {
     if (M <= 64) return G2_64x64_4W;  // skinny (time MLP, AdaLN stack over the NFE steps): weight-streaming, no row reuse to gain
     struct Cand { int id, bm, bn; float t; };
-    static const Cand cands[] = {{G2_128x192_8W, 128, 192, 19.3f}, {G2_128x128_8W, 128, 128, 14.5f},
+    // (256x128: 865 TFLOP/s at M = 16384, N = 2048 against 722 for 128x128: the many-utterance batches C3 / C4)
+    static const Cand cands[] = {{G2_256x128_8W, 256, 128, 21.0f}, {G2_128x192_8W, 128, 192, 19.3f}, {G2_128x128_8W, 128, 128, 14.5f},
                                  {G2_128x64_8W, 128, 64, 7.3f}, {G2_64x64_4W, 64, 64, 4.0f}};
     int best = G2_64x64_4W;
     float best_cost = 3.0e38f;
@@ -33,6 +34,7 @@ template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                  const Epi& epi, int cfg) {
     switch (cfg) {
+        case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
