@@ -38,7 +38,8 @@ __device__ __forceinline__ float group_max(float v) {
 template <int STAGE_IDX, bool EDGE, int VAR>
 __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_base, int k_off, int kc0, int kc1, int v_off, int vc,
                                            const u32x4 (&qf)[2][2], f32x4 (&o)[4][2], float (&mrun)[2], float (&lrun)[2],
-                                           int key_base, int kv_len) {
+                                           int key_base, int kv_len, bool first) {
+    constexpr bool LAZY = (VAR & 4) != 0;
     constexpr int TILE = 64 * 128;
     constexpr float L2E = 1.4426950408889634f;
     const unsigned sb = lds_base + STAGE_IDX * (2 * TILE);
@@ -61,7 +62,12 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qs = 0; qs < 2; ++qs) {
+            // LAZY: q arrives pre-scaled by log2(e) and the accumulators start at -reference, so the MFMAs deliver
+            // log2-unit scores already relative to the running reference: no multiply, no subtract per score
+            const float c0 = LAZY ? -mrun[qs] : 0.f;
+            s[ks][qs] = f32x4{c0, c0, c0, c0};
+        }
     if (VAR & 1) {
         __builtin_amdgcn_sched_barrier(0);
         wait_lgkm<6>(kf[0][0], kf[0][1]);
@@ -79,6 +85,69 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[1][ks], qf[qs][1], s[ks][qs]);
     // ---- online softmax over this wave's keys (lane group g owns keys key_base + 4 ks + r)
+    if (LAZY) {
+        // Softmax is shift-invariant: any per-query reference c works as long as 2^(s - c) stays in range.  c follows the
+        // running maximum only when a tile exceeds it by more than 2^LAZY_THR (and on the first tile, where it is SET to
+        // the tile maximum), so after the first tiles the per-score work is max -> exp2 -> add: p <= 2^LAZY_THR = 256.
+        constexpr float LAZY_THR = 8.0f;
+        // Fast test "does any score of this tile exceed the reference by more than LAZY_THR": for a positive threshold,
+        // s > THR  <=>  (int)bits(s) > (int)bits(THR) (positive floats order like their bit patterns, negative floats are
+        // negative integers, NaNs of either sign land in the slow path or are ignored like fmaxf would), so the tile
+        // maximum is an INTEGER max3 tree: no canonicalising v_max on the MFMA results.  The float maximum itself is
+        // only needed on the slow path.
+        int imax[2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            if (EDGE) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + ks * 4 + r >= kv_len) s[ks][qs][r] = -1e30f;
+            }
+            auto bits = [](float x) { return __builtin_bit_cast(int, x); };
+            int m = max(max(max(bits(s[0][qs][0]), bits(s[0][qs][1])), max(bits(s[0][qs][2]), bits(s[0][qs][3]))),
+                        max(max(bits(s[1][qs][0]), bits(s[1][qs][1])), max(bits(s[1][qs][2]), bits(s[1][qs][3]))));
+            imax[qs] = m;
+        }
+        const int thr_bits = __builtin_bit_cast(int, LAZY_THR);
+        const bool upd = first || imax[0] > thr_bits || imax[1] > thr_bits;   // per lane; any lane of the wave -> slow path
+        if (__builtin_expect(__any(upd), 0)) {  // wave-uniform, rare after the first tiles: move the reference, rescale l and O
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float mloc = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
+                                   fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
+                mloc = group_max(mloc);           // the 4 lane groups of a query column agree on its maximum ...
+                const float dq = (first || mloc > LAZY_THR) ? mloc : 0.f;   // ... and therefore on the new reference
+                // (first tile: l and O are still zero and dq may be the -1e30 of a fully masked tile: keep alpha finite)
+                const float alpha = __builtin_amdgcn_exp2f(-fmaxf(dq, 0.f));
+                mrun[qs] += dq;
+                lrun[qs] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[ks][qs][r] -= dq;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha;
+                }
+            }
+        }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(s[ks][qs][r]);
+                    if (EDGE && key_base + ks * 4 + r >= kv_len) p = 0.f;
+                    s[ks][qs][r] = p;
+                    psum += p;
+                }
+            lrun[qs] += psum;
+        }
+    } else {
     float alpha[2];
     bool grew = false;
 #pragma unroll
@@ -128,6 +197,7 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
             for (int dt = 0; dt < 4; ++dt) {
                 o[dt][qs][0] *= alpha[qs]; o[dt][qs][1] *= alpha[qs]; o[dt][qs][2] *= alpha[qs]; o[dt][qs][3] *= alpha[qs];
             }
+    }
     }
     // ---- O^T += V^T P^T: one 32-key MFMA step; lane group g supplies keys 8g .. 8g+7 of this wave's half on both sides
     u32x4 pf2[2];
@@ -197,7 +267,8 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     const bf16_t* ksrc = K + bh * (size_t)N * 64 + kchunk * 8;
     const bf16_t* vsrc = Vt + (bh * 64 + vrow) * (size_t)Npad + vchunk * 8;
     auto issue = [&](int kt, int stage) {
-        const int t = min(kt, nkt - 1);
+        if (kt >= nkt) return;   // nothing past the last tile: no dummy load to wait for at the end
+        const int t = kt;
         char* base = smem + stage * STAGE;
         const int key = min(t * 64 + krow, N - 1);        // rows past N are clamped; their scores are masked
         glds16(ksrc + (size_t)key * 64, base + wave * 1024);
@@ -209,7 +280,8 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) o[dt][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    // running reference (log2 units): LAZY starts at 0 and SETS it on the first tile; the exact-max path starts at -inf
+    float mrun[2] = {(VAR & 4) ? 0.f : -1e30f, (VAR & 4) ? 0.f : -1e30f}, lrun[2] = {0.f, 0.f};
 
     // fragment read offsets (stage base and sub-tile strides are compile-time immediates in attn2_tile)
     const int ka = l15 >> 2, kb = l15 & 3;
@@ -229,10 +301,10 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     int kt = 0;
 #define F5_ATTN_STEP(SI, EDGE_)                                                                                        \
     {                                                                                                                  \
-        wait_vmcnt<(NS - 2) * L>();                                                                                    \
+        if (kt + 1 < nkt) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();                                            \
         __builtin_amdgcn_s_barrier();                                                                                  \
         issue(kt + NS - 1, (SI + NS - 1) % NS);                                                                        \
-        attn2_tile<SI, EDGE_, VAR>(smem, lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len);        \
+        attn2_tile<SI, EDGE_, VAR>(smem, lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len, kt == 0);        \
         ++kt;                                                                                                          \
     }
     while (kt + 3 <= nfull) {
@@ -245,8 +317,7 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     if (kt < nkt) { if (kt < nfull) F5_ATTN_STEP(1, false) else F5_ATTN_STEP(1, true) }
     if (kt < nkt) { F5_ATTN_STEP(2, true) }
 #undef F5_ATTN_STEP
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // every wave is done with the ring: reuse it for the pair merge
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring (and no load is in flight): reuse it for the pair merge
 
     // ---- merge the two key halves of each query group (kh = 1 publishes, kh = 0 combines and stores)
 #pragma unroll
@@ -293,8 +364,12 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     }
 }
 
-// diagnostic switch (bit 0: asm LDS reads + counted waits, bit 1: asm max3 / permlane swaps)
-inline int& attn2_variant() { static int v = 3; return v; }
+// diagnostic switch (bit 0: asm LDS reads + counted waits, bit 1: permlane swaps, bit 2: lazy softmax reference with q
+// pre-scaled by log2 e).  Producers of q must use attention_q_scale<T>().
+inline int& attn2_variant() { static int v = 7; return v; }
+template <typename T> inline float attention_q_scale();   // dim_head^-0.5 (x log2 e where the kernel works in log2 units)
+template <> inline float attention_q_scale<float>() { return 0.125f; }
+template <> inline float attention_q_scale<bf16_t>() { return (attn2_variant() & 4) ? 0.125f * 1.4426950408889634f : 0.125f; }
 inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp, int H,
                                     int N, int Npad, const int* kv_lens, int nbatch_lens) {
     constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
@@ -312,9 +387,8 @@ inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const
         hipLaunchKernelGGL(attn2_fwd_kernel<V>, grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens); \
     }
     if (var == 0) F5_ATTN2_LAUNCH(0)
-    else if (var == 1) F5_ATTN2_LAUNCH(1)
-    else if (var == 2) F5_ATTN2_LAUNCH(2)
-    else F5_ATTN2_LAUNCH(3)
+    else if (var == 3) F5_ATTN2_LAUNCH(3)
+    else F5_ATTN2_LAUNCH(7)
 #undef F5_ATTN2_LAUNCH
     return hipGetLastError();
 }

@@ -709,7 +709,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, 0.125f}));
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
@@ -804,7 +804,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
         HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, 0.125f}));
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B));

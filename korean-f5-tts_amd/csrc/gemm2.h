@@ -6,14 +6,15 @@
 //     (16-byte chunk c of row r lives in slot c ^ (r & 7));
 //   * NS-stage ring (NS-1 K-tiles issued ahead), ONE raw s_barrier per K-tile, counted `s_waitcnt vmcnt(N)` that only
 //     retires the tile about to be consumed -- the loads of the next NS-2 tiles stay in flight across the barrier;
-//   * tail handling without branches: past the last K-tile the loaders re-issue the last tile into stages nobody reads
-//     again (keeps the vmcnt arithmetic constant); rows beyond M / N are clamped (their results are never stored).
+//   * tail: nothing is requested past the last K-tile (a dummy load would cost one more L2 round trip before the
+//     workgroup may retire); the vmcnt allowance shrinks with the tiles left (one scalar branch per K-tile);
+//     rows beyond M / N are clamped (their results are never stored).
 // Requirements: K % (128 / sizeof(T)) == 0 (the engine pads K), lda/ldw multiples of 16 bytes.
 #pragma once
 #include "gemm.h"
 
 #ifndef F5_GEMM_SPREAD_DMA
-#define F5_GEMM_SPREAD_DMA 0  // measured: out 9.1 -> 9.5 us, ff2 15.1 -> 16.4 us (tools/gemm2_sweep.py): off
+#define F5_GEMM_SPREAD_DMA 0  // (would also need the kt + NS - 1 < nkt guard of issue()) measured: out 9.1 -> 9.5 us, ff2 15.1 -> 16.4 us (tools/gemm2_sweep.py): off
 #endif
 
 namespace f5 {
@@ -133,11 +134,21 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         if (p < LA) glds16(asrc[p] + koff, base + (wave + p * NW) * 1024);
         else glds16(wsrc[p - LA] + koff, base + BM * GEMM_ROW_BYTES + (wave + (p - LA) * NW) * 1024);
     };
+    // (tiles past the end are never requested: a dummy tail load would have to be waited for before the workgroup may
+    // retire its LDS -- one more L2 round trip at the end of every launch)
     auto issue = [&](int kt, int stage) {
+        if (kt >= nkt) return;
         char* base = smem + stage * STAGE;
-        const int koff = min(kt, nkt - 1) * KT;
+        const int koff = kt * KT;
 #pragma unroll
         for (int p = 0; p < L; ++p) issue_piece(p, koff, base);
+    };
+    // wait until at most `tiles` (<= NS-2) of this wave's requested tiles are still in flight
+    auto wait_tiles = [&](int tiles) {
+        if (tiles >= NS - 2) wait_vmcnt<(NS - 2) * L>();
+        else if (NS >= 4 && tiles == NS - 3) wait_vmcnt<(NS >= 4 ? NS - 3 : 0) * L>();
+        else if (NS >= 5 && tiles == NS - 4) wait_vmcnt<(NS >= 5 ? NS - 4 : 0) * L>();
+        else wait_vmcnt<0>();
     };
 
     f32x4 acc[MI][NJ];
@@ -171,7 +182,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         constexpr int R = 2 * (MI + NJ);
         int stage = 0;
         for (int kt = 0; kt < nkt; ++kt) {
-            if (MODE != 2) wait_vmcnt<(NS - 2) * L>();  // this wave's pieces of tile kt have landed ...
+            if (MODE != 2) wait_tiles(nkt - 1 - kt);  // this wave's pieces of tile kt have landed (later tiles may be in flight) ...
             __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
             int pf = stage + NS - 1;
             if (pf >= NS) pf -= NS;
@@ -179,7 +190,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
             // and 25-60 in the gaps of the MFMA stream: the L pieces of tile kt+NS-1 are spread over the MFMA rows.
             constexpr bool SPREAD = F5_GEMM_SPREAD_DMA && MODE == 0;
             char* pbase = smem + pf * STAGE;
-            const int pkoff = min(kt + NS - 1, nkt - 1) * KT;
+            const int pkoff = (kt + NS - 1) * KT;
             if (MODE != 2 && !SPREAD) issue(kt + NS - 1, pf);
             if (MODE != 1) {
                 // all fragment reads of the K-tile are issued first, in the order the MFMAs consume them:
@@ -236,8 +247,16 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     } else {
         kloop(std::integral_constant<int, 0>{});
     }
-    wait_vmcnt<0>();  // drain the dummy tail loads before the block's LDS can be reallocated
 
+    if (MODE == 4 && K > 0) {  // diagnostic: no epilogue (K <= 0 never happens; keeps the accumulators alive)
+        float sink = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sink == 1234.5678f && lda < 0) *reinterpret_cast<volatile float*>(smem) = sink;
+        return;
+    }
     const int mw = m0 + wr * TM, nw = n0 + wc * TN;
     bool any_row = false, any_tr = false;
 #pragma unroll

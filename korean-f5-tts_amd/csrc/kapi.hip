@@ -123,7 +123,7 @@ static int attn_impl(const float* q, const float* k, const float* v, const int32
         HIPCHK(hipMemcpy(ld.p, lens_host, (size_t)Bp * 4, hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL((pack_qkv_test_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, q, k, v, qd.p, kd.p, vd.p, rows,
-                       N, Npad, 0.125f);
+                       N, Npad, attention_q_scale<T>());
     KCHK();
     HIPCHK(launch_attention_any(s, qd.p, kd.p, vd.p, od.p, Bp, H, N, Npad, lens_host ? ld.p : nullptr, Bp));
     hipLaunchKernelGGL((to_f32_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, od.p, out, rows * 64);
@@ -201,6 +201,8 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         // diagnostic floors of config 2 (outputs are garbage): 1xx = DMA only, 2xx = compute only
         case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
         case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 402: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 4>(s, A, lda, W, ldw, M, N, K, epi);  // no epilogue
+        case 409: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 4>(s, A, lda, W, ldw, M, N, K, epi);
         default: return hipErrorInvalidValue;
     }
 }

@@ -86,6 +86,42 @@ def test_attention_key_padding_mask_and_peaked_softmax(prec, tol):
     assert (out - ref).abs().max() < tol
 
 
+def _as_operands(prec, q, k, v):
+    """What the kernel multiplies: the bf16 path rounds k, v and q * attention_q_scale (dim_head^-0.5 * log2 e, attn2.h)
+    to bf16.  With scores of magnitude 100+ that operand rounding moves the softmax far more than any kernel-internal
+    arithmetic, so the extreme-score cases compare against SDPA of the ROUNDED operands."""
+    if prec != "bf16":
+        return q, k, v
+    qs = 0.125 * 1.4426950408889634
+    return (q * qs).bfloat16().float() / qs, k.bfloat16().float(), v.bfloat16().float()
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2.5e-2)])
+def test_attention_reference_tracking_extremes(prec, tol):
+    """The bf16 kernel keeps a lazily updated softmax reference (attn2.h): scores that keep growing tile after tile
+    (reference moves many times), scores that are all very negative (the first-tile reference must follow DOWN or the
+    row underflows to 0/0), and rows whose valid keys end inside the first tile / first key half."""
+    g = torch.Generator().manual_seed(11)
+    Bp, H, N = 2, 2, 520
+    q, k, v = (torch.randn(Bp, H, N, 64, generator=g).to(DEV) for _ in range(3))
+    ramp = torch.linspace(0.2, 6.0, N, device=DEV)
+    k_grow = k * ramp[None, None, :, None]                  # later keys score higher and higher
+    out = k_attention(prec, q, k_grow, v)
+    assert torch.isfinite(out).all()
+    assert (out - sdpa_ref(*_as_operands(prec, q, k_grow, v))).abs().max() < tol
+    k_neg = k.clone()
+    k_neg[..., 0] = 40.0
+    q_neg = q.clone()
+    q_neg[..., 0] = -q_neg[..., 0].abs() * 8.0 - 8.0         # every score is about -40 .. -400 after the 1/8
+    out = k_attention(prec, q_neg, k_neg, v)
+    assert torch.isfinite(out).all()
+    assert (out - sdpa_ref(*_as_operands(prec, q_neg, k_neg, v))).abs().max() < tol
+    lens = [5, 40]                                           # 5 < 32: the second key half of tile 0 is fully masked
+    out = k_attention(prec, q, k, v, lens)
+    assert torch.isfinite(out).all()
+    assert (out - sdpa_ref(q, k, v, lens)).abs().max() < tol
+
+
 @pytest.mark.parametrize("D,N,Bp", [(256, 48, 2), (1024, 300, 2), (512, 129, 1), (1024, 1024, 2)])
 @pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
 def test_convpos_matches_conv1d_mish(D, N, Bp, prec, tol):
