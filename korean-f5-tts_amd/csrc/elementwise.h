@@ -20,14 +20,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const float* xr = x + (size_t)r * ldx;
-    float4 v[8];
-    float s = 0.f;
+    float4 v[8], ga[8], gb[8];
+    // the modulation / affine vectors do not depend on the statistics: request them together with the row so that the
+    // kernel is ONE memory round trip deep, not two
+    const size_t vb = (size_t)(rows_per_batch > 0 ? r / rows_per_batch : 0) * vec_stride;
+    const float a0 = modulate ? 0.f : 1.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = lane * 4 + i * 256;
         v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        ga[i] = (A && c < D) ? *reinterpret_cast<const float4*>(A + vb + c) : make_float4(a0, a0, a0, a0);
+        gb[i] = (Bv && c < D) ? *reinterpret_cast<const float4*>(Bv + vb + c) : make_float4(0, 0, 0, 0);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -39,13 +46,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    const size_t vb = (size_t)(rows_per_batch > 0 ? r / rows_per_batch : 0) * vec_stride;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = lane * 4 + i * 256;
         if (c < D) {
-            float4 a = A ? *reinterpret_cast<const float4*>(A + vb + c) : make_float4(modulate ? 0.f : 1.f, modulate ? 0.f : 1.f, modulate ? 0.f : 1.f, modulate ? 0.f : 1.f);
-            const float4 b = Bv ? *reinterpret_cast<const float4*>(Bv + vb + c) : make_float4(0, 0, 0, 0);
+            float4 a = ga[i];
+            const float4 b = gb[i];
             if (modulate) { a.x += 1.f; a.y += 1.f; a.z += 1.f; a.w += 1.f; }
             store4(out + (size_t)r * ldo + c, (v[i].x - mean) * rstd * a.x + b.x, (v[i].y - mean) * rstd * a.y + b.y,
                    (v[i].z - mean) * rstd * a.z + b.z, (v[i].w - mean) * rstd * a.w + b.w);

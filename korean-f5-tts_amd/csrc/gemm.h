@@ -45,7 +45,9 @@ template <> struct Mma<float> {
 // index, position, masks -- this is where the integer divisions live), a COLUMN context (once per 4-column group:
 // bias, head, ...) and a store that combines them:
 //   RowCtx row(m) / ColCtx col(n)                      row-packed orientation: v[r] = C[m][n + r]      (n % 4 == 0)
-//   void   store(RowCtx, ColCtx, v)
+//   Pre    preload(RowCtx, ColCtx)                    operands the store needs from memory (residual, gate): requested
+//                                                     BEFORE the K loop by the v2 kernel so the epilogue is not a round trip deep
+//   void   store(RowCtx, ColCtx, v, Pre)
 //   TRowCtx trow(m, M) / TColCtx tcol(n)               transposed orientation: v[r] = C[m + r][n]      (m % 4 == 0)
 //   void   tstore(TRowCtx, TColCtx, v)                 -- only reached if tile_transposed() can be true
 struct NoCtx {};
@@ -67,7 +69,9 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     __device__ __forceinline__ ColCtx col(int n) const {
         return {bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0), n};
     }
-    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v) const {
+    typedef NoCtx Pre;
+    __device__ __forceinline__ NoCtx preload(const RowCtx&, const ColCtx&) const { return {}; }
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v, const NoCtx&) const {
         const int a = ACT >= 0 ? ACT : act;
         store4(r.p + c.n, apply_act(v[0] + c.b.x, a), apply_act(v[1] + c.b.y, a), apply_act(v[2] + c.b.z, a),
                apply_act(v[3] + c.b.w, a));
@@ -111,10 +115,15 @@ struct EpiGateRes {
     __device__ __forceinline__ ColCtx col(int n) const {
         return {bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0), n};
     }
-    __device__ __forceinline__ void store(const RowCtx& rc, const ColCtx& c, f32x4 v) const {
-        float4 r = *reinterpret_cast<const float4*>(res + rc.off + c.n);
+    struct Pre { float4 r, g; };
+    __device__ __forceinline__ Pre preload(const RowCtx& rc, const ColCtx& c) const {
+        return {*reinterpret_cast<const float4*>(res + rc.off + c.n),
+                rc.g ? *reinterpret_cast<const float4*>(rc.g + c.n) : make_float4(1, 1, 1, 1)};
+    }
+    __device__ __forceinline__ void store(const RowCtx& rc, const ColCtx& c, f32x4 v, const Pre& p) const {
+        float4 r = p.r;
         if (!rc.masked) {
-            const float4 g = rc.g ? *reinterpret_cast<const float4*>(rc.g + c.n) : make_float4(1, 1, 1, 1);
+            const float4 g = p.g;
             r.x += g.x * (v[0] + c.b.x); r.y += g.y * (v[1] + c.b.y);
             r.z += g.z * (v[2] + c.b.z); r.w += g.w * (v[3] + c.b.w);
         }
@@ -148,11 +157,16 @@ template <typename TO> struct EpiQKV {
         return {*reinterpret_cast<const float4*>(bias + n), which ? k : q, (size_t)h * Nseq * 64 + d, d, h < pe_heads,
                 which ? 1.0f : q_scale};
     }
-    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v) const {
+    struct Pre { float2 cs, sn; };
+    __device__ __forceinline__ Pre preload(const RowCtx& r, const ColCtx& c) const {
+        if (!c.rot) return {make_float2(1, 1), make_float2(0, 0)};
+        return {*reinterpret_cast<const float2*>(r.cs + (c.d >> 1)), *reinterpret_cast<const float2*>(r.sn + (c.d >> 1))};
+    }
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v, const Pre& p) const {
         float a0 = v[0] + c.b.x, a1 = v[1] + c.b.y, a2 = v[2] + c.b.z, a3 = v[3] + c.b.w;
         if (c.rot) {
-            const float2 cs = *reinterpret_cast<const float2*>(r.cs + (c.d >> 1));
-            const float2 sn = *reinterpret_cast<const float2*>(r.sn + (c.d >> 1));
+            const float2 cs = p.cs;
+            const float2 sn = p.sn;
             const float r0 = a0 * cs.x - a1 * sn.x, r1 = a1 * cs.x + a0 * sn.x;
             const float r2 = a2 * cs.y - a3 * sn.y, r3 = a3 * cs.y + a2 * sn.y;
             a0 = r0; a1 = r1; a2 = r2; a3 = r3;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, i
             const typename Epi::RowCtx rc = epi.row(m);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                if (nw + j * 16 + (lane >> 4) * 4 < N) epi.store(rc, cc[j], acc[i][j]);
+                if (nw + j * 16 + (lane >> 4) * 4 < N) epi.store(rc, cc[j], acc[i][j], epi.preload(rc, cc[j]));
         }
     } else {
 #pragma unroll

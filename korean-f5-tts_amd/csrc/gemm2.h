@@ -165,6 +165,41 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     const int c0 = ((0 + g) ^ sw) * 16, c1 = ((4 + g) ^ sw) * 16;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte address of smem
 
+    // Epilogue contexts and the memory operands of the store (bias, residual, gate, rotary table) are set up and REQUESTED
+    // here, before the first tile: their latency hides under the K loop instead of adding a round trip after it.  They
+    // are older than every LDS-DMA piece, so the counted vmcnt waits of the loop retire them first.  Large wave tiles
+    // cannot afford the registers (the 256x128 tile spilled): they set the epilogue up after the loop.
+    constexpr int PRE_WORDS = sizeof(typename Epi::Pre) >= 4 ? (int)sizeof(typename Epi::Pre) / 4 : 0;
+    constexpr bool EARLY = MI * NJ * (1 + PRE_WORDS) <= 64;
+    const int mw = m0 + wr * TM, nw = n0 + wc * TN;
+    bool any_row = false, any_tr = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { any_row |= !trj[j]; any_tr |= trj[j]; }
+    typename Epi::RowCtx rc[MI];
+    typename Epi::ColCtx cc[NJ];
+    typename Epi::Pre pre[MI][NJ];
+    typename Epi::TRowCtx trc[MI];
+    typename Epi::TColCtx tcc[NJ];
+    auto epilogue_setup = [&]() {
+        if (any_row) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) rc[i] = epi.row(min(mw + i * 16 + l15, M - 1));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                cc[j] = epi.col(min(nw + j * 16 + g * 4, N - 4));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pre[i][j] = epi.preload(rc[i], cc[j]);
+            }
+        }
+        if (any_tr) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) trc[i] = epi.trow(min(mw + i * 16 + g * 4, M - 1), M);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) tcc[j] = epi.tcol(min(nw + j * 16 + l15, N - 1));
+        }
+    };
+    if (EARLY) epilogue_setup();
+
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t, t);
 
@@ -257,36 +292,23 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         if (sink == 1234.5678f && lda < 0) *reinterpret_cast<volatile float*>(smem) = sink;
         return;
     }
-    const int mw = m0 + wr * TM, nw = n0 + wc * TN;
-    bool any_row = false, any_tr = false;
+    if (!EARLY) epilogue_setup();
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { any_row |= !trj[j]; any_tr |= trj[j]; }
-    if (any_row) {
-        typename Epi::RowCtx rc[MI];
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nw + j * 16 + g * 4;
+        if (trj[j] || n >= N) continue;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) rc[i] = epi.row(min(mw + i * 16 + l15, M - 1));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = nw + j * 16 + g * 4;
-            if (trj[j] || n >= N) continue;
-            const typename Epi::ColCtx cc = epi.col(n);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                if (mw + i * 16 + l15 < M) epi.store(rc[i], cc, acc[i][j]);
-        }
+        for (int i = 0; i < MI; ++i)
+            if (mw + i * 16 + l15 < M) epi.store(rc[i], cc[j], acc[i][j], pre[i][j]);
     }
     if (any_tr) {
-        typename Epi::TRowCtx rc[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) rc[i] = epi.trow(min(mw + i * 16 + g * 4, M - 1), M);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = nw + j * 16 + l15;
             if (!trj[j] || n >= N) continue;
-            const typename Epi::TColCtx cc = epi.tcol(n);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                if (mw + i * 16 + g * 4 < M) epi.tstore(rc[i], cc, acc[i][j]);
+                if (mw + i * 16 + g * 4 < M) epi.tstore(trc[i], tcc[j], acc[i][j]);
         }
     }
 }
