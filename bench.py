@@ -140,7 +140,9 @@ def main():
     model = P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(dev)
     voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
     cond_cpu, text_cpu, durs, refs = make_inputs(P, args, rank)
-    cond, text = cond_cpu.to(dev), text_cpu.to(dev)
+    # the prompt mel is resident in HBM; the text ids stay on the host (the reference's API takes list[str]: their
+    # length feeds host-side duration arithmetic, cfm.py:125-141, and a device copy would force a D2H sync per call)
+    cond, text = cond_cpu.to(dev), text_cpu
     eng = tr.engine()
     eng.reserve(args.batch, args.frames, args.nfe)
     N, ref, B = args.frames, args.ref_frames, args.batch
@@ -180,6 +182,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, wav = step()
+    t_enq = time.perf_counter()   # (diagnostic only: when the host finished enqueueing; the metric uses `elapsed`)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -207,6 +210,25 @@ def main():
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }
+
+    # ---- diagnostic split of one step (after the timed region, not part of the metric): where a slow run loses its time
+    phases = {"host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3}
+    ps, pv = [], []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        o_, _ = model.sample(cond, text, dur_t, lens=lens_t, **kw)
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        if uniform:
+            voc.decode(o_[:, ref:, :].permute(0, 2, 1))
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        ps.append((b - a) * 1e3)
+        pv.append((c - b) * 1e3)
+    phases["sample_ms_min_max"] = [min(ps), max(ps)]
+    phases["vocos_ms_min_max"] = [min(pv), max(pv)]
+    result["phases"] = phases
 
     if rank == 0:
         # ---- roofline of the dominant kernel class (MFMA GEMMs), per-launch HIP events on the launch stream, in a

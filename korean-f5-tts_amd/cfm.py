@@ -97,12 +97,12 @@ class CFM(nn.Module):
                 torch.manual_seed(seed)
             y0.append(torch.randn(dur, self.num_channels, device=self.noise_device if self.noise_device == "cpu" else device,
                                   dtype=torch.float32))
-        y0 = pad_sequence(y0, padding_value=0, batch_first=True).to(device)
+        y0 = pad_sequence(y0, padding_value=0, batch_first=True)   # stays where it was drawn; Engine.sample copies it asynchronously
 
         t_start = 0
         if duplicate_test:
             t_start = t_inter
-            y0 = (1 - t_start) * y0 + t_start * test_cond
+            y0 = (1 - t_start) * y0.to(device) + t_start * test_cond
             steps = int(steps * (1 - t_start))
         if t_start == 0 and use_epss:
             t = get_epss_timesteps(steps, device="cpu", dtype=torch.float32)

@@ -25,6 +25,16 @@ def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _h2d_async(t: torch.Tensor, device, dtype) -> torch.Tensor:
+    """Host tensor -> device without blocking the host: a pageable `.to(device)` waits for everything already queued on
+    the stream (the previous utterance's whole ODE solve), which serialises the host's per-call work with the GPU.
+    Staged through torch's caching pinned allocator (it keeps the block alive until the copy has executed)."""
+    t = t.detach().to(dtype).contiguous()
+    if t.device.type != "cpu":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def aux_tables(dim_head: int, max_pos: int, text_dim: int, text_pos_rows: int) -> dict[str, torch.Tensor]:
     """Host-computed constant tables, evaluated with the same torch fp32 ops the reference uses:
     rotary angles (x_transformers RotaryEmbedding as called at dit.py:184,311; restated in-repo at
@@ -134,10 +144,10 @@ class Engine:
         """cond f32[B,N,mel] (padded), cond_mask bool[B,N], y0 f32[B,N,mel], text i64[B,nt], t_grid list[float]."""
         B, N, mel = cond.shape
         steps = len(t_grid) - 1
-        cond = _dev_f32(cond, self.device)
-        y0 = _dev_f32(y0, self.device)
-        cm = cond_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        text = text.to(device=self.device, dtype=torch.long).contiguous()
+        cond = _h2d_async(cond, self.device, torch.float32)
+        y0 = _h2d_async(y0, self.device, torch.float32)
+        cm = _h2d_async(cond_mask, self.device, torch.uint8)
+        text = _h2d_async(text, self.device, torch.long)
         out = torch.empty(B, N, mel, device=self.device, dtype=torch.float32)
         traj = torch.empty(steps + 1, B, N, mel, device=self.device, dtype=torch.float32) if want_traj else None
         with torch.cuda.device(self.device):
