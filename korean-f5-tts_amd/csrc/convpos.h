@@ -5,12 +5,15 @@
 //
 // One block = one (batch row, group, 128-token tile).  The block's input window (128 + 30 halo tokens x CPG channels)
 // is converted to the MFMA operand type and kept in LDS for all 31 taps; the packed weights Wp[co][31*CPG] (engine
-// repacks torch's [co][ci][tap] at load time) stream through a double-buffered LDS tile exactly like gemm.h's W operand.
+// repacks torch's [co][ci][tap] at load time) stream through an 8-stage LDS-DMA ring exactly like gemm2.h's W operand
+// (global_load_lds, XOR-swizzled unpadded [rows][128 B] image, counted vmcnt, one raw barrier per K-tile).  The K loop
+// is 31 short steps (16 MFMAs per wave each), so it is bound by how far ahead the weight tiles are requested: with a
+// register-staged double buffer every step waited a full L2 round trip (33 us per launch at D = 1024, N = 1024).
 // The im2col row of a token is never materialised: the fragment for k-chunk (tap, ci0) of token t is simply the
 // 16 bytes at LDS row (t + tap), column ci0.
 // Masking (batched inference, modules.py:187-192): tokens >= lens[b] read as zero and produce zero.
 #pragma once
-#include "gemm.h"
+#include "gemm2.h"
 
 namespace f5 {
 
@@ -27,17 +30,51 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);    // k elements per weight tile (128 bytes)
     constexpr int EPC = 16 / sizeof(T);
     constexpr int NJ = CPG / 16;
-    constexpr int WCH = (CPG * 8 + 255) / 256;
-    constexpr int WBUF = CPG * GEMM_ROW_STRIDE;
-    char* xs = smem;
-    char* ws = smem + XR * XRS;
+    constexpr int NS = 8;                             // weight ring stages
+    constexpr int WTILE = CPG * GEMM_ROW_BYTES;       // bytes of one weight K-tile (CPG rows x 128 B)
+    constexpr int PIECES = CPG / 8;                   // 1 KiB LDS-DMA pieces per tile
+    constexpr int L = PIECES >= 4 ? PIECES / 4 : 1;   // pieces per wave per tile (fewer pieces than waves: duplicates)
+    char* ws = smem;                                  // ring first: 1 KiB-aligned DMA destinations
+    char* xs = smem + NS * WTILE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tok0 = blockIdx.x * TM, grp = blockIdx.y, b = blockIdx.z;
     const int len = lens ? min(N, lens[b % nbatch_lens]) : N;
-    const int nkt = (Kp + KT - 1) / KT;
+    const int nkt = Kp / KT;                          // the engine pads Kp to whole K-tiles with zero weights
 
-    // ---- stage the input window (fp32 -> T)
+    // ---- weight ring: wave w stages pieces (w + 4 i) % PIECES of every tile; lane -> row lane>>3 of the piece, source
+    // chunk (lane & 7) ^ (row & 7) so that chunk c of row r lands in slot c ^ (r & 7)
+    const int lr = lane >> 3;
+    const T* wsrc[L];
+    int wdst[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int piece = (wave + 4 * i) % PIECES;
+        const int row = piece * 8 + lr;
+        wsrc[i] = Wp + (size_t)(grp * CPG + row) * Kp + ((lane & 7) ^ (row & 7)) * EPC;
+        wdst[i] = piece * 1024;
+    }
+    auto issue = [&](int kt, int stage) {
+        if (kt >= nkt) return;
+#pragma unroll
+        for (int i = 0; i < L; ++i) glds16(wsrc[i] + (size_t)kt * KT, ws + stage * WTILE + wdst[i]);
+    };
+    auto wait_tiles = [&](int tiles) {  // at most `tiles` of this wave's requested tiles may still be in flight
+        switch (tiles < NS - 2 ? tiles : NS - 2) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<1 * L>(); break;
+            case 2: wait_vmcnt<2 * L>(); break;
+            case 3: wait_vmcnt<3 * L>(); break;
+            case 4: wait_vmcnt<4 * L>(); break;
+            case 5: wait_vmcnt<5 * L>(); break;
+            default: wait_vmcnt<6 * L>(); break;
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t, t);
+
+    // ---- stage the input window (fp32 -> T) while the first weight tiles are in flight
     for (int c = tid; c < XR * (CPG / 4); c += 256) {
         const int row = c / (CPG / 4), c4 = c % (CPG / 4);
         const int tok = tok0 - 15 + row;
@@ -45,25 +82,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         if (tok >= 0 && tok < len) v = *reinterpret_cast<const float4*>(X + ((size_t)b * N + tok) * D + grp * CPG + c4 * 4);
         store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, v.x, v.y, v.z, v.w);
     }
-
-    u32x4 rw[WCH];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256, row = c >> 3, cc = c & 7;
-            const int ke = kt * KT + cc * EPC;
-            rw[i] = (c < CPG * 8 && ke < Kp)
-                        ? *reinterpret_cast<const u32x4*>(Wp + (size_t)(grp * CPG + row) * Kp + ke)
-                        : u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + i * 256, row = c >> 3, cc = c & 7;
-            if (c < CPG * 8) *reinterpret_cast<u32x4*>(ws + buf * WBUF + row * GEMM_ROW_STRIDE + cc * 16) = rw[i];
-        }
-    };
+    __syncthreads();   // (also retires the window's global loads, which are older than nothing the ring counts below:
+                       //  the compiler waits vmcnt(0) for them, i.e. for the first NS-1 weight tiles too -- once)
 
     f32x4 acc[2][NJ];
 #pragma unroll
@@ -71,12 +91,15 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    sstore(0);
-    __syncthreads();
+    const int wsw = l15 & 7;
+    int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload(kt + 1);
-        const char* Ws = ws + (kt & 1) * WBUF + l15 * GEMM_ROW_STRIDE + g * 16;
+        wait_tiles(nkt - 1 - kt);          // this wave's pieces of tile kt have landed ...
+        __builtin_amdgcn_s_barrier();      // ... everyone's have, and stage (kt-1) % NS is free again
+        int pf = stage + NS - 1;
+        if (pf >= NS) pf -= NS;
+        issue(kt + NS - 1, pf);
+        const char* Ws = ws + stage * WTILE + l15 * GEMM_ROW_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // im2col k index of this lane's 16-byte chunk -> (tap, ci0)
@@ -87,14 +110,14 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
             for (int i = 0; i < 2; ++i)
                 xf[i] = *reinterpret_cast<const u32x4*>(xs + (wave * 32 + i * 16 + l15 + tap) * XRS + ci0 * sizeof(T));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const u32x4*>(Ws + j * 16 * GEMM_ROW_STRIDE + kk * 64);
+            for (int j = 0; j < NJ; ++j)
+                wf[j] = *reinterpret_cast<const u32x4*>(Ws + j * 16 * GEMM_ROW_BYTES + (((kk * 4 + g) ^ wsw) * 16));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
         }
-        if (kt + 1 < nkt) sstore((kt + 1) & 1);
-        __syncthreads();
+        stage = stage + 1 == NS ? 0 : stage + 1;
     }
 
 #pragma unroll
@@ -121,7 +144,9 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
 template <typename T, int CPG>
 inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
                                      const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
-    constexpr int smem = (128 + 32) * (CPG * (int)sizeof(T) + 16) + 2 * CPG * GEMM_ROW_STRIDE;
+    constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
+    if (Kp % KT != 0) return hipErrorInvalidValue;   // weights must be padded to whole K-tiles
+    constexpr int smem = 8 * CPG * GEMM_ROW_BYTES + (128 + 32) * (CPG * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG>),

@@ -370,6 +370,19 @@ static __global__ void zero_tail_rows_kernel(float* __restrict__ h, int B, int N
 }
 
 // --------------------------------------------------------------------------------------- weight repacking
+// Conv1d weight [R = out channels][A = in channels per group][31 taps] (torch) -> implicit-GEMM operand
+// out[r][tap * A + a], rows zero-padded to ld_out (a whole number of 128-byte K-tiles, convpos.h)
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ in, T* __restrict__ out, long R, int A, int Bd, int ld_out) {
+    const long total = R * ld_out;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ld_out);
+        const long r = i / ld_out;
+        const int a = k % A, bd = k / A;
+        out[i] = bd < Bd ? from_f32<T>(in[(r * A + a) * Bd + bd]) : from_f32<T>(0.f);
+    }
+}
+
 // in [R][A][Bd] fp32 -> out [R][Bd][A] (T)
 template <typename T>
 __global__ void permute_last2_kernel(const float* __restrict__ in, T* __restrict__ out, long R, int A, int Bd) {

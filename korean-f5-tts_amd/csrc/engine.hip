@@ -404,14 +404,14 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
     // input embedding
     CHK(pack_linear<T>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj));
     const int cpg = D / 16;
-    P.conv_kp = 31 * cpg;
+    P.conv_kp = round_up(31 * cpg, GEMM_ROW_BYTES / (int)sizeof(T));   // whole K-tiles, zero padded (convpos.h)
     for (int j = 0; j < 2; ++j) {
         const std::string p = "input_embed.conv_pos_embed.conv1d." + std::to_string(j * 2);
         const Tensor* w = nullptr;
         CHK(need(e->ws, p + ".weight", {D, cpg, 31}, &w));
         CHK(dev_alloc(e, &P.conv_w[j], (size_t)D * P.conv_kp));
-        hipLaunchKernelGGL((permute_last2_kernel<T>), dim3(ew_blocks((long)D * P.conv_kp)), dim3(256), 0, s, w->p,
-                           P.conv_w[j], (long)D, cpg, 31);
+        hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(ew_blocks((long)D * P.conv_kp)), dim3(256), 0, s, w->p,
+                           P.conv_w[j], (long)D, cpg, 31, P.conv_kp);
         CHK(copy_vec(e, s, p + ".bias", {D}, &P.conv_b[j]));
     }
     // transformer

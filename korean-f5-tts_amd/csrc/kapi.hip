@@ -143,7 +143,7 @@ extern "C" int f5k_attention(int32_t prec, const float* q, const float* k, const
 template <typename T>
 static int convpos_impl(const float* x, const float* w, const float* bias, const float* res, const int32_t* lens_host, float* y,
                         int Bp, int N, int D, hipStream_t s) {
-    const int cpg = D / 16, Kp = 31 * cpg;
+    const int cpg = D / 16, Kp = round_up(31 * cpg, GEMM_ROW_BYTES / (int)sizeof(T));
     Scratch<T> wp;
     Scratch<int> ld;
     HIPCHK(wp.alloc((size_t)D * Kp));
@@ -151,7 +151,7 @@ static int convpos_impl(const float* x, const float* w, const float* bias, const
         HIPCHK(ld.alloc(Bp));
         HIPCHK(hipMemcpy(ld.p, lens_host, (size_t)Bp * 4, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL((permute_last2_kernel<T>), dim3(ew_blocks((long)D * Kp)), dim3(256), 0, s, w, wp.p, (long)D, cpg, 31);
+    hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(ew_blocks((long)D * Kp)), dim3(256), 0, s, w, wp.p, (long)D, cpg, 31, Kp);
     KCHK();
     HIPCHK(launch_convpos<T>(s, x, wp.p, Kp, bias, res, y, Bp, N, D, lens_host ? ld.p : nullptr, Bp));
     HIPCHK(hipStreamSynchronize(s));
@@ -201,6 +201,12 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         // diagnostic floors of config 2 (outputs are garbage): 1xx = DMA only, 2xx = compute only
         case 102: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
         case 202: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 16: return launch_gemm2_cfg<T, 128, 128, 2, 4, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);   // 64 KB LDS: 2 workgroups per CU
+        case 17: return launch_gemm2_cfg<T, 256, 128, 4, 2, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);   // 96 KB
+        case 18: return launch_gemm2_cfg<T, 128, 128, 2, 2, 2, Epi>(s, A, lda, W, ldw, M, N, K, epi);   // 4 waves, 64 KB: 2 per CU
+        case 113: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 1>(s, A, lda, W, ldw, M, N, K, epi);
+        case 213: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 2>(s, A, lda, W, ldw, M, N, K, epi);
+        case 413: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 4>(s, A, lda, W, ldw, M, N, K, epi);
         case 402: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 4>(s, A, lda, W, ldw, M, N, K, epi);  // no epilogue
         case 409: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 4>(s, A, lda, W, ldw, M, N, K, epi);
         default: return hipErrorInvalidValue;
