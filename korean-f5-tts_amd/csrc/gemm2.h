@@ -210,7 +210,8 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // branches around every MFMA (measured +11 us on the 2048x3072x1024 QKV projection).
     // Tried on top of this loop and dropped (tools/gemm2_sweep.py, M = 2048, cold weights): (a) staggering waves 4-7
     // half a block behind waves 0-3 so that SIMD partners alternate LDS reads and MFMAs: 13.8 -> 15.5 us on FF1;
-    // (b) a second fragment set so that block kt reads tile kt+1 while it multiplies tile kt: +-2 % everywhere.
+    // (b) a second fragment set so that block kt reads tile kt+1 while it multiplies tile kt: +-2 % at M = 2048 and
+    //     -9 % at M = 16384 (664 -> 605 TFLOP/s on 128x128; the 256x128 tile does not fit the registers).
     // Neither the LDS read burst nor the MFMA issue bounds these shapes: the L2 -> LDS fill does (MODE 1).
     auto kloop = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;  // number of trailing transposed sub-tiles (compile-time per loop copy)
