@@ -112,6 +112,41 @@ def test_base_arch_sample_vs_oracle_mid_size():
     assert e16 < TOL_BF16
 
 
+@pytest.mark.parametrize("B,durs,refs,nts", [
+    (1, [1], [1], [1]),            # degenerate: one frame (duration is raised to max(text, prompt) + 1 = 2)
+    (1, [7], [3], [2]),            # shorter than the conv halo (15) and than one MFMA tile
+    (1, [33], [9], [40]),          # text longer than the audio -> duration raised to 41 (cfm.py:125-131)
+    (1, [65], [64], [5]),          # one frame past a 64-key attention tile; almost everything is prompt
+    (2, [129, 17], [40, 16], [11, 3]),    # ragged batch across a 128-row GEMM tile edge, short item nearly all prompt
+    (3, [200, 96, 1], [50, 95, 1], [20, 30, 1]),   # three lengths, one item degenerate
+])
+def test_ragged_and_edge_sizes_vs_oracle(B, durs, refs, nts):
+    """Edge sizes the golden fixtures do not hold (the reference has no unit tests for these; the oracle, pinned on the
+    fixtures, is the checker): tiny / odd N, N straddling kernel tile edges, text longer than audio, ragged batches."""
+    meta, _ = load_golden("sample_b1_nfe16")
+    arch, nv = meta["arch"], meta["nvocab"]
+    sd = synthetic_weights(meta)
+    g = torch.Generator().manual_seed(sum(durs) + 7 * B)
+    rmax, tmax = max(refs), max(nts)
+    cond = torch.zeros(B, rmax, 100)
+    text = torch.full((B, tmax), -1, dtype=torch.long)
+    for i in range(B):
+        cond[i, :refs[i]] = torch.randn(refs[i], 100, generator=g)
+        text[i, :nts[i]] = torch.randint(0, nv - 1, (nts[i],), generator=g)
+    kw = dict(steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3, lens=torch.tensor(refs))
+    dur = torch.tensor(durs)
+    o_out, o_traj = O.sample(sd, arch, cond, text, dur, **kw)
+    model = build_cfm(meta, sd, "f32")
+    out, traj = model.sample(cond, text, dur, **kw)
+    assert out.shape == o_out.shape and traj.shape == o_traj.shape
+    e = (traj.cpu() - o_traj).abs().max().item()
+    print(f"[edge sizes f32] B={B} durs={durs}: traj Linf {e:.3e}")
+    assert e < TOL_PARITY and (out.cpu() - o_out).abs().max() < TOL_PARITY
+    m16 = build_cfm(meta, sd, "bf16")
+    out16, traj16 = m16.sample(cond, text, dur, **kw)
+    assert torch.isfinite(traj16).all() and (traj16.cpu() - o_traj).abs().max() < TOL_BF16
+
+
 def test_full_size_properties():
     """BASELINE config C2 size (N=1024, NFE=16): size-independent properties instead of an oracle run."""
     arch = P.config.F5TTS_BASE
