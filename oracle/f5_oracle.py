@@ -399,7 +399,7 @@ def euler_odeint(fn, y0, t):
 
 def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
            seed=None, max_duration=65536, use_epss=True, no_ref_audio=False, edit_mask=None, backbone="DiT",
-           y0=None):
+           y0=None, duplicate_test=False, t_inter=0.1):
     """cfm.py:83-229 for mel-in / mel-out (cond f32[b, n, mel]; text i64[b, nt] padded -1).
 
     `y0` overrides the noise draw (cfm.py:196-201) so identical noise can be fed to the HIP path and to this oracle.
@@ -417,6 +417,8 @@ def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.
     duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)
     duration = duration.clamp(max=max_duration)
     n = int(duration.amax())
+    if duplicate_test:  # cfm.py:141-143
+        test_cond = F.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
     cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
     if no_ref_audio:
         cond = torch.zeros_like(cond)
@@ -434,7 +436,12 @@ def sample(W, cfg, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.
 
     if y0 is None:
         y0 = draw_noise(duration, cond.shape[-1], seed)
-    t = time_grid(steps, sway_sampling_coef, use_epss)
+    t_start = 0.0
+    if duplicate_test:  # cfm.py:203-208: start the solve at t_inter from a blend of noise and the prompt shifted by its length
+        t_start = t_inter
+        y0 = (1 - t_start) * y0 + t_start * test_cond
+        steps = int(steps * (1 - t_start))
+    t = time_grid(steps, sway_sampling_coef, use_epss, t_start)
     traj = euler_odeint(fn, y0, t)
     out = torch.where(cond_mask, cond, traj[-1])
     return out, traj

@@ -30,7 +30,12 @@ def weights_checksum(sd):
     return float(sum(v.double().abs().sum().item() for v in sd.values()))
 
 
+ONLY = set(sys.argv[1:])   # optional fixture names: regenerate just these
+
+
 def save(name, meta, **arrays):
+    if ONLY and name not in ONLY:
+        return
     arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
     arrs["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
@@ -46,7 +51,8 @@ def build(arch, backbone="DiT", seed=0):
 
 
 def sample_case(name, arch, *, B, cond_len, nt, duration, lens=None, steps, cfg_strength=2.0, sway=-1.0, seed=7,
-                use_epss=True, no_ref_audio=False, edit_mask=None, backbone="DiT", text_pad=None, wseed=0):
+                use_epss=True, no_ref_audio=False, edit_mask=None, backbone="DiT", text_pad=None, wseed=0,
+                duplicate_test=False, t_inter=0.1):
     model, sd = build(arch, backbone, wseed)
     g = torch.Generator().manual_seed(1000 + len(name))
     cond = torch.randn(B, cond_len, 100, generator=g)
@@ -60,11 +66,14 @@ def sample_case(name, arch, *, B, cond_len, nt, duration, lens=None, steps, cfg_
         kw["lens"] = torch.tensor(lens)
     if edit_mask is not None:
         kw["edit_mask"] = edit_mask
+    if duplicate_test:
+        kw.update(duplicate_test=True, t_inter=t_inter)
     dur = duration if isinstance(duration, int) else torch.tensor(duration)
     out, traj = model.sample(cond, text, dur, **kw)
     meta = dict(arch=arch, backbone=backbone, nvocab=NVOCAB, wseed=wseed, steps=steps, cfg_strength=cfg_strength,
                 sway=sway, seed=seed, use_epss=use_epss, no_ref_audio=no_ref_audio,
-                duration=duration, lens=lens, weights_checksum=weights_checksum(sd))
+                duration=duration, lens=lens, weights_checksum=weights_checksum(sd),
+                duplicate_test=duplicate_test, t_inter=t_inter)
     arrays = dict(cond=cond, text=text, out=out, traj=traj)
     if edit_mask is not None:
         arrays["edit_mask"] = edit_mask
@@ -144,6 +153,8 @@ def main():
     sample_case("sample_b1_nocfg_linspace", tiny, B=1, cond_len=16, nt=8, duration=40, steps=8, cfg_strength=0.0,
                 sway=None, use_epss=False)
     sample_case("sample_b1_textclamp", tiny, B=1, cond_len=10, nt=30, duration=12, steps=5)  # duration raised to nt+1
+    # cfm.py:141-143,203-208: solve started at t_inter from noise blended with the prompt; steps shrink to int(8 * 0.8)
+    sample_case("sample_b1_duplicate", tiny, B=1, cond_len=18, nt=9, duration=52, steps=8, duplicate_test=True, t_inter=0.2)
     forward_taps_case("dit_forward_taps", tiny, B=1, N=48, nt=20, masked=False)
     forward_taps_case("dit_forward_taps_masked", tiny, B=2, N=40, nt=20, masked=True)
     e2_tiny = dict(dim=256, depth=4, heads=4, dim_head=64, ff_mult=2, text_mask_padding=False, pe_attn_head=1,

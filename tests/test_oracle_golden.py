@@ -10,7 +10,7 @@ TOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order only
 
 SAMPLE_CASES = ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_b1_editmask",
                 "sample_b1_norefaudio", "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp",
-                "sample_unett_b2"]
+                "sample_b1_duplicate", "sample_unett_b2"]
 
 
 def run_oracle_sample(meta, a, sd, **over):
@@ -24,6 +24,8 @@ def run_oracle_sample(meta, a, sd, **over):
     if "edit_mask" in a:
         kw["edit_mask"] = a["edit_mask"]
     kw.update(over)
+    if meta.get("duplicate_test"):
+        kw.update(duplicate_test=True, t_inter=meta["t_inter"])
     return O.sample(sd, meta["arch"], a["cond"], a["text"], dur, **kw)
 
 

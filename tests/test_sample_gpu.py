@@ -17,7 +17,7 @@ TOL_PARITY = 1e-3   # BASELINE.json north_star: "within 1e-3 mel L-inf"
 TOL_BF16 = 8e-2     # bf16 operands (8-bit mantissa) through depth x NFE compounding; reported, loosely gated
 
 CASES = ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_b1_editmask", "sample_b1_norefaudio",
-         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp", "sample_unett_b2"]
+         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp", "sample_b1_duplicate", "sample_unett_b2"]
 
 
 def build_cfm(meta, sd, precision):
@@ -37,6 +37,8 @@ def run_case(meta, a, model):
         kw["lens"] = torch.tensor(meta["lens"])
     if "edit_mask" in a:
         kw["edit_mask"] = a["edit_mask"]
+    if meta.get("duplicate_test"):
+        kw.update(duplicate_test=True, t_inter=meta["t_inter"])
     return model.sample(a["cond"], a["text"], dur, **kw)
 
 
