@@ -31,6 +31,7 @@
 #include "convpos.h"
 #include "elementwise.h"
 #include "gemm_dispatch.h"
+#include "lnfold.h"
 
 using namespace f5;
 
@@ -217,6 +218,7 @@ struct f5_engine {
     std::vector<std::string> warm;      // signatures (without cache state) that have run eagerly once
     hipStream_t cap_stream = nullptr;
     int graphs_on = -1;                 // -1: read F5_HIP_GRAPH from the environment on first use
+    int ln_fold = -1;                   // -1: read F5_LN_FOLD (lnfold.h; bf16 DiT sample() only; default off)
     // The conditional and unconditional halves of a CFG forward are independent until the Euler update: run them as two
     // concurrent kernel chains (second stream, fork/join events) so that one chain's launch ramps / drains overlap
     // the other chain's main loops.  Opt-in with F5_SPLIT_CFG=1 (see split_cfg_enabled).
@@ -495,6 +497,7 @@ template <typename T> struct Work {
     T* acat;
     float *h, *c1, *x, *pred;
     T *xn, *q, *k, *vt, *ao, *ffh;
+    float *stat, *foldv;   // lnfold.h: row partial sums [rows][LNFOLD_SLOTS][2]; c1/c2 vectors [steps][depth][fold_layer_floats]
     T* cat2;         // UNetT concat buffer [rows, 2D]
     float* skips;    // UNetT skip stack
     float* pred_all; // UNetT proj_out over N+1 tokens
@@ -539,6 +542,8 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.ao = a.take<T>(rows * e->inner);
     w.vt = a.take<T>(Bp * c.heads * 64 * w.Npad);
     w.ffh = a.take<T>(rows * F);
+    w.stat = a.take<float>(rows * LNFOLD_SLOTS * 2);
+    w.foldv = a.take<float>(SS * (size_t)c.depth * 2 * (3 * e->inner + F));
     w.in_cond = a.take<float>((size_t)B * N * mel);
     w.y = a.take<float>((size_t)B * N * mel);
     w.out_buf = a.take<float>((size_t)B * N * mel);
@@ -673,7 +678,8 @@ static int run_text_embed(f5_engine* e, Work<T>& w, const int64_t* text, int B, 
 template <typename T>
 static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N,
                            const float* mod_row, int mod_stride, const int* lens_dev, int drop_cond_first,
-                           const float* text_first, const float* text_second, hipStream_t s) {
+                           const float* text_first, const float* text_second, hipStream_t s,
+                           const float* fold_row = nullptr) {
     Packed<T>& P = packed<T>(e);
     const f5_config& c = e->cfg;
     const int D = c.dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim, H = c.heads;
@@ -699,36 +705,79 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
+    // AdaLayerNorm folded into the neighbouring GEMMs (lnfold.h): 5 launches per block instead of 7
+    constexpr bool CAN_FOLD = std::is_same<T, bf16_t>::value;   // the exact-f32 precision keeps the reference's op order
+    const bool fold = CAN_FOLD && fold_row != nullptr && mod_stride == 0;
+    const int gr_cols = gemm_cfg_wave_cols(pick_cfg_v2(rows, D));          // wave-tile width of the EpiGateResLN launches
+    const int gr_parts = (D + gr_cols - 1) / gr_cols, gr_stride = gr_cols / 16;
+    const size_t FV = 2 * ((size_t)3 * inner + F);
+    if constexpr (CAN_FOLD) if (fold) {
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((fold_prep_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D,
+                           mod_row + D, w.stat);
+        KCHK();
+        pr.end(s);
+    }
     for (int l = 0; l < c.depth; ++l) {
         BlockW<T>& bw = P.blocks[l];
         const float* m = mod_row + (size_t)l * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        pr.begin(PC_LN, s);
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
-                           m + D, m, mod_stride, N, 1);
-        KCHK();
-        pr.end(s);
+        const float* fv = fold ? fold_row + (size_t)l * FV : nullptr;   // c1q, c2q, c1f, c2f
+        if (!fold) {
+            pr.begin(PC_LN, s);
+            hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
+                               m + D, m, mod_stride, N, 1);
+            KCHK();
+            pr.end(s);
+        }
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()}));
+        if constexpr (CAN_FOLD) if (fold) {
+            EpiQKV<T> in{w.q, w.k, w.vt, fv + 3 * inner, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()};
+            HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                                  EpiFold<EpiQKV<T>>{in, fv, w.stat, l == 0 ? 1 : gr_parts, l == 0 ? 1 : gr_stride, 1.0f / D, 1e-6f}));
+        }
+        if (!fold) {
+            HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                                  EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()}));
+        }
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
-        HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, lens_dev}));
-        pr.end(s);
-        pr.begin(PC_LN, s);
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
-                           m + 4 * D, m + 3 * D, mod_stride, N, 1);
-        KCHK();
+        if constexpr (CAN_FOLD) if (fold) {
+            HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+                                  EpiGateResLN<T>{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, lens_dev, w.xn, D, m + 4 * D, w.stat}));
+        }
+        if (!fold) {
+            HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+                                  EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, lens_dev}));
+            pr.end(s);
+            pr.begin(PC_LN, s);
+            hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
+                               m + 4 * D, m + 3 * D, mod_stride, N, 1);
+            KCHK();
+        }
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(F, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        if constexpr (CAN_FOLD) if (fold) {
+            EpiStore<T> in{w.ffh, F, fv + 2 * (size_t)3 * inner + F, F5_ACT_GELU_TANH};
+            HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D,
+                                  EpiFold<EpiStore<T>>{in, fv + 2 * (size_t)3 * inner, w.stat, gr_parts, gr_stride, 1.0f / D, 1e-6f}));
+        }
+        if (!fold) {
+            HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        }
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, F));
-        HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
-                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}));
+        if constexpr (CAN_FOLD) if (fold) {   // next consumer: the first LayerNorm of block l + 1 (none after the last block: norm_out stays a kernel)
+            const float* next_scale = l + 1 < c.depth ? mod_row + (size_t)(l + 1) * 6 * D + D : nullptr;
+            HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
+                                  EpiGateResLN<T>{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr, w.xn, D, next_scale, w.stat}));
+        }
+        if (!fold) {
+            HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
+                                  EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}));
+        }
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
@@ -838,14 +887,53 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     return F5_OK;
 }
 
+// lnfold.h: is the folded path on for this engine?  Opt-in (F5_LN_FOLD=1; bf16 DiT with dim <= 16 * LNFOLD_SLOTS):
+// measured at C2 it removes the two 5.5 us LayerNorm launches of a block but adds 2.6 us to each residual GEMM (A' and
+// partial-sum writes), 1.5-2.5 us to each consumer (statistics prologue, wider epilogue contexts) and the per-utterance
+// c1/c2 pass -- no net gain (42.3 vs 35.0 ms before tuning the helpers, ~34.4 projected after), so it is not the default.
+static bool ln_fold_enabled(f5_engine* e) {
+    if (e->ln_fold < 0) {
+        const char* v = getenv("F5_LN_FOLD");
+        e->ln_fold = (v && v[0] == '1') ? 1 : 0;
+    }
+    const f5_config& c = e->cfg;
+    return e->ln_fold == 1 && c.backbone == F5_BACKBONE_DIT && c.precision == F5_PREC_BF16 && c.dim <= 16 * LNFOLD_SLOTS &&
+           c.dim % 64 == 0;
+}
+
+// c1 / c2 of every block's two folded LayerNorms for the S time steps of w.mod (after run_time_path)
+template <typename T> static int run_fold_vectors(f5_engine* e, Work<T>& w, int S, hipStream_t s) {
+    Packed<T>& P = packed<T>(e);
+    const f5_config& c = e->cfg;
+    const int D = c.dim, F = c.ff_dim, inner = e->inner;
+    const size_t FV = 2 * ((size_t)3 * inner + F), fstep = (size_t)c.depth * FV;
+    e->prof.begin(PC_TIME, s);
+    for (int l = 0; l < c.depth; ++l) {
+        BlockW<T>& bw = P.blocks[l];
+        const float* m = w.mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        float* fv = w.foldv + (size_t)l * FV;
+        hipLaunchKernelGGL((fold_vectors_kernel<T>), dim3((3 * inner + 31) / 32), dim3(256), 0, s, bw.qkv.w, bw.qkv.ldw, bw.qkv.b,
+                           3 * inner, D, m + D, m, (long)e->modN, S, fv, fv + 3 * inner, (long)fstep);
+        hipLaunchKernelGGL((fold_vectors_kernel<T>), dim3((F + 31) / 32), dim3(256), 0, s, bw.ff1.w, bw.ff1.ldw, bw.ff1.b, F, D,
+                           m + 4 * D, m + 3 * D, (long)e->modN, S, fv + 2 * (size_t)3 * inner, fv + 2 * (size_t)3 * inner + F,
+                           (long)fstep);
+    }
+    KCHK();
+    e->prof.end(s);
+    return F5_OK;
+}
+
 // dispatches one backbone forward; `step_row` selects the time step's vectors inside the per-call tables
 template <typename T>
 static int run_backbone(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N, int step_row,
                         int per_row_time, const int* lens_dev, int drop_cond_first, const float* text_first,
-                        const float* text_second, hipStream_t s) {
-    if (e->cfg.backbone == F5_BACKBONE_DIT)
+                        const float* text_second, hipStream_t s, bool fold_steps = false) {
+    if (e->cfg.backbone == F5_BACKBONE_DIT) {
+        const size_t fstep = (size_t)e->cfg.depth * 2 * (3 * e->inner + e->cfg.ff_dim);
         return run_dit_forward<T>(e, w, y, cond, B, Bp, N, w.mod + (size_t)step_row * e->modN, per_row_time ? e->modN : 0,
-                                  lens_dev, drop_cond_first, text_first, text_second, s);
+                                  lens_dev, drop_cond_first, text_first, text_second, s,
+                                  (fold_steps && !per_row_time) ? w.foldv + (size_t)step_row * fstep : nullptr);
+    }
     return run_unett_forward<T>(e, w, y, cond, B, Bp, N, w.temb + (size_t)step_row * e->cfg.dim, per_row_time ? e->cfg.dim : 0,
                                 lens_dev, drop_cond_first, text_first, text_second, s);
 }
@@ -949,6 +1037,7 @@ template <typename T> static Work<T> second_half(const f5_engine* e, const Work<
     h.x = w.x + rows * c.dim;
     h.pred = w.pred + rows * c.mel_dim;
     h.xn = w.xn + rows * c.dim;
+    h.stat = w.stat + rows * LNFOLD_SLOTS * 2;
     h.q = w.q + rows * e->inner;
     h.k = w.k + rows * e->inner;
     h.ao = w.ao + rows * e->inner;
@@ -985,6 +1074,8 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
     KCHK();
     e->prof.end(s);
     CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
+    const bool fold_steps = ln_fold_enabled(e);
+    if (fold_steps) CHK(run_fold_vectors<T>(e, w, steps, s));
     const int* tlens = c.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
     CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
     if (use_cfg) {
@@ -1022,12 +1113,12 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
             HIPCHK(hipEventRecord(e->ev_fork, s));            // y of this step (and, first time, the text embeddings) ready
             HIPCHK(hipStreamWaitEvent(s1, e->ev_fork, 0));
             // conditional chain on s, unconditional chain (cond dropped, filler text) on the side stream
-            CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, B, N, i, 0, lens_dev, 0, w.text_c, w.text_c, s));
-            CHK(run_backbone<T>(e, w2, w.y, w.step_cond, B, B, N, i, 0, lens_dev, 1, w.text_u, w.text_u, s1));
+            CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, B, N, i, 0, lens_dev, 0, w.text_c, w.text_c, s, fold_steps));
+            CHK(run_backbone<T>(e, w2, w.y, w.step_cond, B, B, N, i, 0, lens_dev, 1, w.text_u, w.text_u, s1, fold_steps));
             HIPCHK(hipEventRecord(e->ev_join, s1));
             HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
         } else
-        CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s));
+        CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s, fold_steps));
         e->prof.begin(PC_MISC, s);
         hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.y, w.pred, half, w.tdev, i,
                            cfg_strength, use_cfg ? 1 : 0, want_traj ? w.traj_buf + (size_t)(i + 1) * half : nullptr);

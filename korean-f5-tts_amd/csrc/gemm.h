@@ -64,6 +64,8 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
     static constexpr bool kTransposes = false;
+    static constexpr int kRowLdsFloats = 0;    // per-row floats the workgroup stages in LDS before the K loop (lnfold.h)
+    static constexpr bool kRowDone = false;    // row_done() hook after the stores (lnfold.h)
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const { return {out + (size_t)m * ldo}; }
     __device__ __forceinline__ ColCtx col(int n) const {
@@ -106,6 +108,8 @@ struct EpiGateRes {
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
     static constexpr bool kTransposes = false;
+    static constexpr int kRowLdsFloats = 0;    // per-row floats the workgroup stages in LDS before the K loop (lnfold.h)
+    static constexpr bool kRowDone = false;    // row_done() hook after the stores (lnfold.h)
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / rows_per_batch;
@@ -146,6 +150,8 @@ template <typename TO> struct EpiQKV {
     struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
     struct TColCtx { float b; size_t hoff; };
     static constexpr bool kTransposes = true;
+    static constexpr int kRowLdsFloats = 0;
+    static constexpr bool kRowDone = false;
     __device__ __forceinline__ bool tile_transposed(int n0) const { return n0 >= 2 * H * 64; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / Nseq, pos = m - b * Nseq;

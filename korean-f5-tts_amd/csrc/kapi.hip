@@ -349,3 +349,71 @@ extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32
     (void)hipEventDestroy(e1);
     return F5_OK;
 }
+
+
+// diagnostic: what a software grid barrier between the phases of a persistent kernel would cost on this part (cross-XCD
+// visibility included: agent-scope release before arriving, acquire after leaving, neighbour's data verified).  Every
+// spin is bounded, so the kernel always terminates; *bad counts timeouts and stale reads.
+__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(unsigned* ctr, unsigned* data, int iters, int payload_floats,
+                                                                 float* payload, unsigned* bad) {
+    const unsigned nb = gridDim.x;
+    unsigned errors = 0;
+    for (int it = 0; it < iters; ++it) {
+        // phase work: each block writes a slice (payload_floats per thread) and its tag
+        for (int p = 0; p < payload_floats; ++p)
+            payload[((size_t)blockIdx.x * payload_floats + p) * blockDim.x + threadIdx.x] = (float)it;
+        if (threadIdx.x == 0) data[blockIdx.x] = (unsigned)it + 1u;
+        __threadfence();                       // release: make this block's writes visible device-wide
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(it + 1) * nb;
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 2000000) { errors += 1000000u; break; }
+            }
+        }
+        __syncthreads();
+        __threadfence();                       // acquire on behalf of the whole block
+        const unsigned nbr = (blockIdx.x + 37u) % nb;   // a block on another XCD (ids are dealt round-robin over 8 XCDs)
+        if (threadIdx.x == 0 && __hip_atomic_load(&data[nbr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)it + 1u) errors++;
+        if (payload_floats > 0) {
+            const float v = payload[((size_t)nbr * payload_floats) * blockDim.x + threadIdx.x];
+            if (v != (float)it) errors++;
+        }
+    }
+    if (errors) atomicAdd(bad, errors);
+}
+
+extern "C" int f5x_grid_barrier_probe(int32_t blocks, int32_t iters, int32_t payload_floats, float* us_per_barrier, int32_t* bad_out,
+                                      f5_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Scratch<unsigned> ctr, data, bad;
+    Scratch<float> payload;
+    HIPCHK(ctr.alloc(1));
+    HIPCHK(bad.alloc(1));
+    HIPCHK(data.alloc(blocks));
+    HIPCHK(payload.alloc((size_t)blocks * std::max(payload_floats, 1) * 512));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {   // first launch warms the code
+        HIPCHK(hipMemsetAsync(ctr.p, 0, 4, s));
+        HIPCHK(hipMemsetAsync(bad.p, 0, 4, s));
+        HIPCHK(hipMemsetAsync(data.p, 0, (size_t)blocks * 4, s));
+        HIPCHK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(blocks), dim3(512), 0, s, ctr.p, data.p, iters, payload_floats, payload.p, bad.p);
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    unsigned b = 0;
+    HIPCHK(hipMemcpy(&b, bad.p, 4, hipMemcpyDeviceToHost));
+    *us_per_barrier = ms * 1000.f / iters;
+    *bad_out = (int32_t)b;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return F5_OK;
+}

@@ -149,6 +149,22 @@ def test_ragged_and_edge_sizes_vs_oracle(B, durs, refs, nts):
     assert torch.isfinite(traj16).all() and (traj16.cpu() - o_traj).abs().max() < TOL_BF16
 
 
+def test_layernorm_fold_option_matches_default_path(monkeypatch):
+    """F5_LN_FOLD=1 (csrc/lnfold.h, opt-in): AdaLayerNorm folded algebraically into the neighbouring GEMMs.  Same
+    arithmetic up to bf16 rounding order: its trajectory must sit as close to the reference vectors as the default path's."""
+    meta, a = load_golden("sample_b3_masked")
+    sd = synthetic_weights(meta)
+    _, traj0 = run_case(meta, a, build_cfm(meta, sd, "bf16"))
+    monkeypatch.setenv("F5_LN_FOLD", "1")          # read once per engine, at its first sample()
+    _, traj1 = run_case(meta, a, build_cfm(meta, sd, "bf16"))
+    e0 = (traj0.cpu() - a["traj"]).abs().max().item()
+    e1 = (traj1.cpu() - a["traj"]).abs().max().item()
+    d = (traj1 - traj0).abs().max().item()
+    print(f"[ln fold] default {e0:.3e}, folded {e1:.3e} vs reference; folded vs default {d:.3e}")
+    assert d > 0, "the folded path did not run"
+    assert e1 < TOL_BF16 and e1 < 2.0 * e0 + 1e-3
+
+
 def test_full_size_properties():
     """BASELINE config C2 size (N=1024, NFE=16): size-independent properties instead of an oracle run."""
     arch = P.config.F5TTS_BASE
