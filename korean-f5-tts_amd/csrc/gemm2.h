@@ -13,10 +13,6 @@
 #pragma once
 #include "gemm.h"
 
-#ifndef F5_GEMM_SPREAD_DMA
-#define F5_GEMM_SPREAD_DMA 0  // (would also need the kt + NS - 1 < nkt guard of issue()) measured: out 9.1 -> 9.5 us, ff2 15.1 -> 16.4 us (tools/gemm2_sweep.py): off
-#endif
-
 namespace f5 {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -224,61 +220,53 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // half a block behind waves 0-3 so that SIMD partners alternate LDS reads and MFMAs: 13.8 -> 15.5 us on FF1;
     // (b) a second fragment set so that block kt reads tile kt+1 while it multiplies tile kt: +-2 % at M = 2048 and
     //     -9 % at M = 16384 (664 -> 605 TFLOP/s on 128x128; the 256x128 tile does not fit the registers).
-    // Neither the LDS read burst nor the MFMA issue bounds these shapes: the L2 -> LDS fill does (MODE 1).
+    // (c) issuing the LDS-DMA pieces between MFMA rows instead of at the head of the block: out 9.1 -> 9.5 us;
+    // (d) two K-tiles per barrier (ring of 6) for the small 128x64 / 64x64 wave tiles: out 10.0 -> 10.3, ff2 17.4 -> 17.1 us.
+    // What these have in common: the K loop tracks the per-CU vector-memory fill path (DMA-only floor 0.32 us per 32 KB
+    // K-step = ~48 B/clk/CU), not barriers, LDS reads or MFMA issue.
     auto kloop = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;  // number of trailing transposed sub-tiles (compile-time per loop copy)
         constexpr int R = 2 * (MI + NJ);
-        int stage = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            if (MODE != 2) wait_tiles(nkt - 1 - kt);  // this wave's pieces of tile kt have landed (later tiles may be in flight) ...
-            __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
-            int pf = stage + NS - 1;
-            if (pf >= NS) pf -= NS;
-            // An LDS-DMA piece costs its wave 100-185 issue cycles at the head of a block (MI355X_MICROARCH.md price list)
-            // and 25-60 in the gaps of the MFMA stream: the L pieces of tile kt+NS-1 are spread over the MFMA rows.
-            constexpr bool SPREAD = F5_GEMM_SPREAD_DMA && MODE == 0;
-            char* pbase = smem + pf * STAGE;
-            const int pkoff = (kt + NS - 1) * KT;
-            if (MODE != 2 && !SPREAD) issue(kt + NS - 1, pf);
-            if (MODE != 1) {
-                // all fragment reads of the K-tile are issued first, in the order the MFMAs consume them:
-                //   per kk: a[0], w[0..NJ-1], a[1..MI-1];  the MFMA row i of kk may start once read (kk*(MI+NJ) + NJ + i) is back
-                u32x4 af[2][MI], wf[2][NJ];
-                const unsigned sbu = (unsigned)(stage * STAGE) + lds_base;
+        // one K-tile: all fragment reads are issued first, in the order the MFMAs consume them:
+        //   per kk: a[0], w[0..NJ-1], a[1..MI-1];  the MFMA row i of kk may start once read (kk*(MI+NJ) + NJ + i) is back
+        auto tile = [&](int stage) {
+            u32x4 af[2][MI], wf[2][NJ];
+            const unsigned sbu = (unsigned)(stage * STAGE) + lds_base;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const unsigned co = kk ? c1 : c0;
-                    lds_read_b128_asm(af[kk][0], sbu + a_row_off + co);
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned co = kk ? c1 : c0;
+                lds_read_b128_asm(af[kk][0], sbu + a_row_off + co);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) lds_read_b128_asm(wf[kk][j], sbu + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
+                for (int j = 0; j < NJ; ++j) lds_read_b128_asm(wf[kk][j], sbu + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
 #pragma unroll
-                    for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
-                }
+                for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
+            }
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        __builtin_amdgcn_sched_barrier(0);  // keep the previous row's MFMAs above this wait
-                        // outstanding reads allowed when row i of kk starts = R - 1 - (index of the last read it needs)
-                        wait_row<R, MI, NJ>(kk, i, af, wf);
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);  // keep the previous row's MFMAs above this wait
+                    // outstanding reads allowed when row i of kk starts = R - 1 - (index of the last read it needs)
+                    wait_row<R, MI, NJ>(kk, i, af, wf);
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            if (j < NJ - NT) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);
-                            else acc[i][j] = Mma<T>::run(af[kk][i], wf[kk][j], acc[i][j]);
-                        }
-                        if (SPREAD) {
-                            constexpr int NR = 2 * MI;
-#pragma unroll
-                            for (int p = 0; p < L; ++p)
-                                if (p * NR / L == kk * MI + i) {
-                                    __builtin_amdgcn_sched_barrier(0);
-                                    issue_piece(p, pkoff, pbase);
-                                }
-                        }
+                    for (int j = 0; j < NJ; ++j) {
+                        if (j < NJ - NT) acc[i][j] = Mma<T>::run(wf[kk][j], af[kk][i], acc[i][j]);
+                        else acc[i][j] = Mma<T>::run(af[kk][i], wf[kk][j], acc[i][j]);
                     }
                 }
             }
-            stage = stage + 1 == NS ? 0 : stage + 1;
+        };
+        int stage = 0;
+        {
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (MODE != 2) wait_tiles(nkt - 1 - kt);  // this wave's pieces of tile kt have landed (later tiles may be in flight) ...
+                __builtin_amdgcn_s_barrier();     // ... and so have everyone else's; stage (kt-1)%NS is free again
+                int pf = stage + NS - 1;
+                if (pf >= NS) pf -= NS;
+                if (MODE != 2) issue(kt + NS - 1, pf);
+                if (MODE != 1) tile(stage);
+                stage = stage + 1 == NS ? 0 : stage + 1;
+            }
         }
     };
     if constexpr (Epi::kTransposes) {
