@@ -6,8 +6,11 @@
 //   pair are merged once at the end through LDS (flash-decoding style):  m = max(m0, m1), O = O0 e^(m0-m) + O1 e^(m1-m).
 //   Two waves per SIMD: one's softmax VALU work overlaps the other's MFMAs (dh = 64 attention is VALU-heavy:
 //   ~0.34 VALU cycles per score vs 0.25 MFMA cycles).
-//   The accumulator rescale by e^(m_old - m_new) is skipped while no lane of the wave sees its running max grow
-//   (exact: the factor is 1), which removes most of the O-wide multiplies after the first few tiles.
+//   Softmax reference (VAR bit 2, the default): q arrives pre-scaled by log2 e (attention_q_scale), the score
+//   accumulators start at -reference, and the reference only moves when a tile exceeds it by 2^8 (or on a wave's first
+//   tile), decided by an integer max3 tree on the score bit patterns; the move (rescale of l and O) is an out-of-line
+//   slow path.  Steady state per score: exp2 + add.  (VAR bit 2 clear: exact running maximum, rescale skipped while
+//   no lane sees its maximum grow.)
 //   Key order inside a 32-key half: MFMA row 4a + b of S^T sub-tile ks is key 8a + 4ks + b, so that lane group g ends
 //   up owning the 8 CONSECUTIVE keys 8g..8g+7 -- its P^T fragment pairs with ONE 16-byte V^T fragment read.
 //   LDS image: K tile [64 keys][128 B], 16-byte chunk c of row r in slot c ^ kswz(r); V^T tile [64 dh][128 B], slot

@@ -6,7 +6,7 @@
 //   xn (LN-modulated), attn out, ffh T   [2B*N, D | inner | F]          T = bf16 (speed) or f32 (parity)
 //   q, k                             T   [2B, H, N, 64]      v^T  T [2B, H, 64, Npad]
 //   mod                              f32 [steps, (6*depth + 2) * D]     all AdaLN vectors of all layers for ALL steps
-// Weights are engine-owned copies: GEMM operands in T ([out, in], K padded to 16 bytes), everything that feeds
+// Weights are engine-owned copies: GEMM operands in T ([out, in], K padded to whole 128-byte K-tiles), everything that feeds
 // fp32-only stages (time MLP, AdaLN stack, text encoder, norms, biases) in f32.
 //
 // What is restructured w.r.t. the reference (results identical up to fp rounding):
