@@ -11,11 +11,17 @@ namespace f5 {
 //   modulate: A = 1 + scale[b(r), :], B = shift[b(r), :]   (AdaLayerNorm, modules.py:314-320,335-341,680-693)
 //   affine  : A = weight, B = bias                         (nn.LayerNorm(dim), modules.py:259; Vocos norms)
 // One wave per row; D <= 2048, D % 4 == 0.  Two-pass statistics in registers (mean, then centred variance).
+//
+// Prefetch: up to two byte ranges (the weights of the GEMMs that follow) are read and discarded, spread over the grid,
+// requested AFTER the row so that they never delay it.  The 370 MB of block weights do not fit the 256 MB Infinity
+// Cache, so every GEMM of a step otherwise starts with HBM-latency misses on its W tiles; this launch is latency-bound
+// and has the memory system to itself.
+struct Prefetch { const char* p0 = nullptr; size_t n0 = 0; const char* p1 = nullptr; size_t n1 = 0; };
 template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out,
                                                         int ldo, int R, int D, float eps, const float* __restrict__ A,
                                                         const float* __restrict__ Bv, int vec_stride,
-                                                        int rows_per_batch, int modulate) {
+                                                        int rows_per_batch, int modulate, Prefetch pf) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -31,6 +37,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
         ga[i] = (A && c < D) ? *reinterpret_cast<const float4*>(A + vb + c) : make_float4(a0, a0, a0, a0);
         gb[i] = (Bv && c < D) ? *reinterpret_cast<const float4*>(Bv + vb + c) : make_float4(0, 0, 0, 0);
+    }
+    u32x4 pfv[8] = {};
+    if (pf.n0 | pf.n1) {
+        const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const size_t off = (gtid + (size_t)(i & 3) * gsz) * 16;   // four 16-byte chunks per thread and range
+            const char* base = i < 4 ? pf.p0 : pf.p1;
+            const size_t n = i < 4 ? pf.n0 : pf.n1;
+            if (off + 16 <= n) pfv[i] = *reinterpret_cast<const u32x4*>(base + off);
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -57,6 +74,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                    (v[i].z - mean) * rstd * a.z + b.z, (v[i].w - mean) * rstd * a.w + b.w);
         }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(pfv[i]));   // keep the prefetch loads; nothing uses their data
 }
 
 // x_transformers.RMSNorm as used by UNetT (unett.py:154,168,185): F.normalize(x, dim=-1) * sqrt(D) * g

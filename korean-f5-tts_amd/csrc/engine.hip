@@ -705,6 +705,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
+    static const bool wpf = !(getenv("F5_WEIGHT_PREFETCH") && getenv("F5_WEIGHT_PREFETCH")[0] == '0');   // see layernorm_kernel
     // AdaLayerNorm folded into the neighbouring GEMMs (lnfold.h): 5 launches per block instead of 7
     constexpr bool CAN_FOLD = std::is_same<T, bf16_t>::value;   // the exact-f32 precision keeps the reference's op order
     const bool fold = CAN_FOLD && fold_row != nullptr && mod_stride == 0;
@@ -725,7 +726,9 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         if (!fold) {
             pr.begin(PC_LN, s);
             hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
-                               m + D, m, mod_stride, N, 1);
+                               m + D, m, mod_stride, N, 1,
+                               wpf ? Prefetch{(const char*)bw.qkv.w, (size_t)3 * inner * bw.qkv.ldw * sizeof(T),
+                                              (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{});
             KCHK();
             pr.end(s);
         }
@@ -754,7 +757,9 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
             pr.end(s);
             pr.begin(PC_LN, s);
             hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
-                               m + 4 * D, m + 3 * D, mod_stride, N, 1);
+                               m + 4 * D, m + 3 * D, mod_stride, N, 1,
+                               wpf ? Prefetch{(const char*)bw.ff1.w, (size_t)F * bw.ff1.ldw * sizeof(T),
+                                              (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{});
             KCHK();
         }
         pr.end(s);
@@ -783,7 +788,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
     pr.begin(PC_LN, s);
     hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f, mf,
-                       mf + D, mod_stride, N, 1);
+                       mf + D, mod_stride, N, 1, Prefetch{});
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(mel, D));

@@ -172,7 +172,7 @@ extern "C" int f5k_layernorm_mod(const float* x, const float* scale, const float
     if (!x || !out || R <= 0 || D <= 0 || D % 4 || D > 2048 || rows_per_batch <= 0) return fail(F5_EINVAL, "f5k_layernorm_mod: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL((layernorm_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, s, x, D, out, D, R, D, eps, scale, shift, D,
-                       rows_per_batch, 1);
+                       rows_per_batch, 1, Prefetch{});
     KCHK();
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
@@ -294,7 +294,7 @@ extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32
     HIPCHK(hipMemsetAsync(sc.p, 0, (size_t)2 * K * 4, s));
     HIPCHK(hipMemsetAsync(w.p, 0x3c, (size_t)ncopy * N * K * 2, s));
     auto ln = [&](T* dst) {
-        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, x.p, K, dst, K, M, K, 1e-6f, sc.p, sc.p + K, 0, M, 1);
+        hipLaunchKernelGGL((layernorm_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, s, x.p, K, dst, K, M, K, 1e-6f, sc.p, sc.p + K, 0, M, 1, Prefetch{});
     };
     auto gm = [&](int i, int c) -> hipError_t {
         return gemm2_dispatch<T>(c, s, xn.p, K, w.p + (size_t)(i % ncopy) * N * K, K, M, N, K, EpiStore<T>{o.p, N, nullptr, F5_ACT_GELU_TANH});

@@ -213,7 +213,7 @@ extern "C" int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t
     KCHK();
     HIPCHK(launch_gemm<float>(s, col, v->kemb, v->emb_w, v->kemb, (int)R, D, v->kemb, EpiStore<float>{t1, D, v->emb_b, F5_ACT_NONE}));
     hipLaunchKernelGGL((layernorm_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, s, t1, D, x, D, (int)R, D, 1e-6f, v->n0w,
-                       v->n0b, 0, 0, 0);
+                       v->n0b, 0, 0, 0, Prefetch{});
     KCHK();
     for (auto& b : v->blocks) {
         hipLaunchKernelGGL(dwconv7_ln_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, t1, b.dwk, b.dwb, b.lnw, b.lnb, B, T, D,
@@ -224,7 +224,7 @@ extern "C" int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t
         HIPCHK(launch_gemm<float>(s, h, I, b.w2, I, (int)R, D, I, EpiGateRes{x, x, D, b.b2, b.gamma, 0, (int)R + 1, nullptr}));
     }
     hipLaunchKernelGGL((layernorm_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, s, x, D, t1, D, (int)R, D, 1e-6f, v->fnw,
-                       v->fnb, 0, 0, 0);
+                       v->fnb, 0, 0, 0, Prefetch{});
     KCHK();
     HIPCHK(launch_gemm<float>(s, t1, D, v->head_w, D, (int)R, v->head_n, D, EpiStore<float>{hd, v->head_n, v->head_b, F5_ACT_NONE}));
     hipLaunchKernelGGL(istft_spec_kernel, dim3(ew_blocks(R * v->K2)), dim3(256), 0, s, hd, v->head_n, S, v->K2, R, v->F);
