@@ -222,8 +222,13 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     //     -9 % at M = 16384 (664 -> 605 TFLOP/s on 128x128; the 256x128 tile does not fit the registers).
     // (c) issuing the LDS-DMA pieces between MFMA rows instead of at the head of the block: out 9.1 -> 9.5 us;
     // (d) two K-tiles per barrier (ring of 6) for the small 128x64 / 64x64 wave tiles: out 10.0 -> 10.3, ff2 17.4 -> 17.1 us.
-    // What these have in common: the K loop tracks the per-CU vector-memory fill path (DMA-only floor 0.32 us per 32 KB
-    // K-step = ~48 B/clk/CU), not barriers, LDS reads or MFMA issue.
+    // Floors of this loop for the 128x128 / 8-wave tile, per 64-deep K-step on a full chip (tools/gemm_scale.py with the
+    // diagnostic MODEs, K = 1024 -> 8192): bare MFMA issue 0.216 us (tools/mfma_rate_probe.py: 2.3-2.4 PFLOP/s at
+    // 2.1-2.37 GHz); + one barrier per step 0.28; + the 12 fragment reads per wave (96 KB of LDS reads per step), however
+    // they are scheduled (up front, register-pipelined a step ahead, or interleaved two per MFMA) 0.385-0.43; LDS-DMA
+    // only 0.32; everything 0.51.  The fragment reads cost ~0.1 us of MFMA issue even when nothing waits on them, so
+    // only a wave tile with fewer reads per MFMA (64x64: the 256x128 configuration) moves this, and M = 2048 cannot
+    // fill the chip with such tiles.
     auto kloop = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;  // number of trailing transposed sub-tiles (compile-time per loop copy)
         constexpr int R = 2 * (MI + NJ);

@@ -417,3 +417,56 @@ extern "C" int f5x_grid_barrier_probe(int32_t blocks, int32_t iters, int32_t pay
     (void)hipEventDestroy(e1);
     return F5_OK;
 }
+
+
+// diagnostic: bare MFMA issue rate and the shader clock it runs at.  Every wave issues `iters` x 8 independent
+// v_mfma_f32_16x16x32_bf16 (operands in registers); s_memtime counts shader clocks, s_memrealtime a constant 100 MHz.
+__global__ __launch_bounds__(512) void mfma_rate_probe_kernel(int iters, unsigned long long* out) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (bf16_t)(float)(threadIdx.x & 7); b[i] = (bf16_t)1.0f; }
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float sink = 0.f;
+    for (int i = 0; i < 8; ++i) sink += acc[i][0] + acc[i][3];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 3 + 0] = c1 - c0;
+        out[blockIdx.x * 3 + 1] = r1 - r0;
+        out[blockIdx.x * 3 + 2] = (unsigned long long)(sink != 12345.678f);
+    }
+}
+
+extern "C" int f5x_mfma_rate_probe(int32_t blocks, int32_t threads, int32_t iters, double* cyc_per_mfma_per_simd, double* mhz,
+                                   double* tflops, f5_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Scratch<unsigned long long> out;
+    HIPCHK(out.alloc((size_t)blocks * 3));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    float ms = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIPCHK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(mfma_rate_probe_kernel, dim3(blocks), dim3(threads), 0, s, iters, out.p);
+        HIPCHK(hipEventRecord(e1, s));
+        HIPCHK(hipEventSynchronize(e1));
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> h((size_t)blocks * 3);
+    HIPCHK(hipMemcpy(h.data(), out.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    for (int b = 0; b < blocks; ++b) { cyc += (double)h[b * 3]; real += (double)h[b * 3 + 1]; }
+    cyc /= blocks; real /= blocks;
+    const int waves_per_simd = (threads / 64 + 3) / 4;
+    *cyc_per_mfma_per_simd = cyc / ((double)iters * 8 * waves_per_simd);
+    *mhz = cyc / (real / 100.0);   // real counts 100 MHz ticks -> microseconds = real / 100
+    *tflops = (double)blocks * (threads / 64) * iters * 8 * 16384.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return F5_OK;
+}

@@ -16,7 +16,7 @@ def run(m, n, k, cfg, prec=1):
 cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2, 8, 9]
 for cfg in cfgs:
     print("cfg", cfg)
-    for k in (1024,):
+    for k in (1024, 8192):
         us = run(2048, 2048, k, cfg); print(f"  K={k:5d}: {us:7.1f}us {2.0*2048*2048*k/us/1e6:7.1f}TF")
-    for m in ((2048, 16384, 65536) if cfg < 100 else (2048, 16384)):
+    for m in ((2048, 16384, 65536) if cfg < 100 else ()):
         us = run(m, 2048, 1024, cfg); print(f"  M={m:5d}: {us:7.1f}us {2.0*m*2048*1024/us/1e6:7.1f}TF")
