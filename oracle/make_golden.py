@@ -124,6 +124,50 @@ def forward_taps_case(name, arch, B, N, nt, masked):
     save(name, meta, **arrays)
 
 
+
+def bucketing_case(name="bucketing"):
+    """Runs the reference's `get_inference_prompt` (eval/utils_eval.py:72-205) on synthetic "files": `torchaudio.load` and
+    `MelSpec` are replaced by fakes that only carry lengths, so the fixture pins the duration formula, the bucket index,
+    the frame-budget batching, the residual flush and the seeded shuffle."""
+    if ONLY and name not in ONLY:
+        return
+    import random
+
+    ev = rh.load_eval()
+    rng = random.Random(12)
+    words = ["hello", "speech", "flow", "matching", "korean", "안녕하세요", "텍스트", "voice", "a", "synthesis."]
+    meta, nsamp = [], {}
+    for i in range(57):
+        secs = rng.uniform(1.2, 9.0)
+        path = f"/fake/prompt_{i}.wav"
+        nsamp[path] = int(secs * 24000)
+        ptext = " ".join(rng.choice(words) for _ in range(rng.randint(3, 9)))
+        gtext = " ".join(rng.choice(words) for _ in range(rng.randint(3, 14)))
+        meta.append((f"utt{i}", ptext, path, gtext, "/fake/none.wav"))
+
+    class FakeMel:
+        def __init__(self, **kw):
+            self.hop = kw["hop_length"]
+
+        def __call__(self, audio):
+            return torch.zeros(1, 100, audio.shape[-1] // self.hop + 1)   # center=True framing
+
+    ev.torchaudio.load = lambda path: (torch.full((1, nsamp[path]), 0.2), 24000)
+    ev.MelSpec = FakeMel
+    cases = []
+    for bs, speed in ((1, 1.0), (3000, 1.0), (6000, 0.8)):
+        out = ev.get_inference_prompt(meta, speed=speed, tokenizer="char", infer_batch_size=bs, min_secs=1, max_secs=120)
+        cases.append(dict(infer_batch_size=bs, speed=speed, min_secs=1, max_secs=120,
+                          batches=[dict(utts=list(b[0]), ref_mel_lens=[int(v) for v in b[3]],
+                                        total_mel_lens=[int(v) for v in b[4]], texts=list(b[5])) for b in out]))
+    fixture = dict(note="eval/utils_eval.py:72-205 run on length-only fakes", hop_length=256, target_sample_rate=24000,
+                   prompts=[dict(utt=m[0], prompt_text=m[1], nsamples=nsamp[m[2]], gt_text=m[3]) for m in meta],
+                   cases=cases)
+    with open(os.path.join(OUT, name + ".json"), "w") as fh:
+        json.dump(fixture, fh, ensure_ascii=False, indent=0)
+    print("wrote", name, [len(c["batches"]) for c in cases])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = rh.load()
@@ -159,6 +203,7 @@ def main():
     forward_taps_case("dit_forward_taps_masked", tiny, B=2, N=40, nt=20, masked=True)
     e2_tiny = dict(dim=256, depth=4, heads=4, dim_head=64, ff_mult=2, text_mask_padding=False, pe_attn_head=1,
                    text_dim=None, conv_layers=0, attn_mask_enabled=False, qk_norm=None)
+    bucketing_case()
     sample_case("sample_unett_b2", e2_tiny, B=2, cond_len=20, nt=12, duration=[44, 31], lens=[20, 12], steps=5,
                 text_pad=[12, 8], backbone="UNetT")
 

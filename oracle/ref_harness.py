@@ -198,3 +198,19 @@ def load_infer():
             sys.modules[pkg] = m
     ref.infer = importlib.import_module("f5_tts.infer.utils_infer")
     return ref.infer
+
+
+def load_eval():
+    """Imports the reference's evaluation helpers (src/f5_tts/eval/utils_eval.py) for pinning the batch bucketing of
+    `get_inference_prompt`.  Its file / DSP dependencies are the inert torchaudio stand-in plus whatever the caller
+    monkeypatches onto the returned module (`torchaudio.load`, `MelSpec`)."""
+    ref = load_infer() and load()
+    if getattr(ref, "eval", None) is not None:
+        return ref.eval
+    for pkg, rel in (("f5_tts.eval", "f5_tts/eval"),):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF_SRC, rel)]
+            sys.modules[pkg] = m
+    ref.eval = importlib.import_module("f5_tts.eval.utils_eval")
+    return ref.eval
