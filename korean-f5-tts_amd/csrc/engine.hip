@@ -490,7 +490,8 @@ extern "C" int f5_finalize(f5_engine* e, f5_stream stream) {
 template <typename T> struct Work {
     // per call
     float *tdev, *feat, *th, *temb, *st, *mod;
-    int* lens;
+    int* lens;        // per-sample lengths, chunk-major: for each chunk of Bc utterances [Bc values][the same Bc values]
+    int* lens_plain;  // the same lengths once, in utterance order (text encoder)
     float *step_cond, *text_c, *text_u, *tx_a, *tx_b, *tx_h1, *grn_part;
     unsigned char* dummy;
     // per forward
@@ -524,6 +525,7 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.st = a.take<float>(SS * D);
     w.mod = a.take<float>(SS * e->modN);
     w.lens = a.take<int>(Bp + 16);
+    w.lens_plain = a.take<int>(Bp + 16);
     w.step_cond = a.take<float>((size_t)B * N * mel);
     w.text_c = a.take<float>((size_t)B * N * Dt);
     w.text_u = a.take<float>((size_t)B * N * Dt);
@@ -943,11 +945,26 @@ static int run_backbone(f5_engine* e, Work<T>& w, const float* y, const float* c
                                 lens_dev, drop_cond_first, text_first, text_second, s);
 }
 
+// Utterances per backbone call inside sample(): the ODE state of different utterances never interacts, so a large batch
+// is stepped in chunks whose activations (x 4 B, xn, q, k, v, ffh 2 B per element: ~17 KB per row) stay inside the 256 MB
+// Infinity Cache between the kernels of a block, instead of streaming every intermediate through HBM (C3: 65,536 rows).
+// F5_CHUNK_ROWS overrides the row budget (tests force tiny chunks).
+static int chunk_utts(const f5_engine* e, int B, int N, bool use_cfg) {
+    static const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 20000;   // (C3: 4,096 / 8,192 / 16,384 / 32,768 / all rows -> 1.76 / 1.53 / 1.48 / 1.55 / 1.58 s)
+    const long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
+    long bc = budget / rows_per_utt;
+    if (bc < 1) bc = 1;
+    if (bc >= B) return B;
+    const long nchunks = (B + bc - 1) / bc;
+    return (int)((B + nchunks - 1) / nchunks);   // equal-sized chunks (8 utterances, budget 7 -> 4 + 4, not 7 + 1)
+}
+
 // lens bookkeeping: uploads per-sample lengths (duplicated for the uncond half) through pinned staging
 template <typename T>
 static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, const int32_t* lens_host, int B,
-                        hipStream_t s) {
-    const size_t bytes = (size_t)nT * 4 + (size_t)2 * B * 4 + 64;
+                        hipStream_t s, int chunk = 0) {
+    if (chunk <= 0 || chunk > B) chunk = B;
+    const size_t bytes = (size_t)nT * 4 + (size_t)3 * B * 4 + 64;
     char* hb = nullptr;
     int slot = 0;
     CHK(e->stage.acquire(bytes, &hb, &slot));
@@ -959,8 +976,13 @@ static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, c
     }
     if (lens_host) {
         const int add = e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0;  // UNetT masks are left-padded for the time token
-        for (int i = 0; i < B; ++i) lh[i] = lh[B + i] = lens_host[i] + add;
+        for (int u0 = 0; u0 < B; u0 += chunk) {   // chunk-major: [cond lens of the chunk][uncond lens of the chunk]
+            const int bc = std::min(chunk, B - u0);
+            for (int i = 0; i < bc; ++i) lh[2 * u0 + i] = lh[2 * u0 + bc + i] = lens_host[u0 + i] + add;
+        }
+        for (int i = 0; i < B; ++i) lh[2 * B + i] = lens_host[i] + add;
         HIPCHK(hipMemcpyAsync(w.lens, lh, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(w.lens_plain, lh + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
     }
     return e->stage.release(slot, s);
 }
@@ -981,7 +1003,7 @@ static int text_embed_impl(f5_engine* e, const int64_t* text, int B, int nt, con
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     CHK(upload_small<T>(e, w, nullptr, 0, lens_host, B, s));
     const bool per_sample = lens_host && e->cfg.backbone == F5_BACKBONE_DIT;  // unett.py embeds at the padded length
-    return run_text_embed<T>(e, w, text, B, nt, per_sample ? w.lens : nullptr, N, drop_text, out, s);
+    return run_text_embed<T>(e, w, text, B, nt, per_sample ? w.lens_plain : nullptr, N, drop_text, out, s);
 }
 
 extern "C" int f5_text_embed(f5_engine* e, const int64_t* text, int32_t B, int32_t nt, const int32_t* lens_host,
@@ -1007,7 +1029,7 @@ static int forward_impl(f5_engine* e, const float* x, const float* cond, const i
     const int* lens_dev = lens_host ? w.lens : nullptr;
     CHK(run_time_path<T>(e, w, Bp, s));
     // UNetT embeds text at the padded length for every sample (unett.py:196-215), DiT at each sample's own length
-    const int* tlens = e->cfg.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
+    const int* tlens = (e->cfg.backbone == F5_BACKBONE_DIT && lens_host) ? w.lens_plain : nullptr;
     if (cfg_infer) {
         CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
         CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 1, w.text_u, s));
@@ -1081,7 +1103,7 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
     CHK(run_time_path<T>(e, w, steps, s));  // features of t[0..steps-1]
     const bool fold_steps = ln_fold_enabled(e);
     if (fold_steps) CHK(run_fold_vectors<T>(e, w, steps, s));
-    const int* tlens = c.backbone == F5_BACKBONE_DIT ? lens_dev : nullptr;
+    const int* tlens = (c.backbone == F5_BACKBONE_DIT && has_lens) ? w.lens_plain : nullptr;
     CHK(run_text_embed<T>(e, w, text, B, nt, tlens, N, 0, w.text_c, s));
     if (use_cfg) {
         const size_t ucn = (size_t)N * c.text_dim;
@@ -1112,6 +1134,7 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
         if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         if (!e->ev_join) HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
+    const int chunk = chunk_utts(e, B, N, use_cfg);   // (sample_impl laid w.lens out for this chunk size)
     for (int i = 0; i < steps; ++i) {
         if (split) {
             hipStream_t s1 = e->side_stream;
@@ -1122,13 +1145,27 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
             CHK(run_backbone<T>(e, w2, w.y, w.step_cond, B, B, N, i, 0, lens_dev, 1, w.text_u, w.text_u, s1, fold_steps));
             HIPCHK(hipEventRecord(e->ev_join, s1));
             HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
-        } else
-        CHK(run_backbone<T>(e, w, w.y, w.step_cond, B, Bp, N, i, 0, lens_dev, 0, w.text_c, use_cfg ? w.text_u : w.text_c, s, fold_steps));
-        e->prof.begin(PC_MISC, s);
-        hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.y, w.pred, half, w.tdev, i,
-                           cfg_strength, use_cfg ? 1 : 0, want_traj ? w.traj_buf + (size_t)(i + 1) * half : nullptr);
-        KCHK();
-        e->prof.end(s);
+            e->prof.begin(PC_MISC, s);
+            hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half / 4)), dim3(256), 0, s, w.y, w.pred, half, w.tdev, i,
+                               cfg_strength, use_cfg ? 1 : 0, want_traj ? w.traj_buf + (size_t)(i + 1) * half : nullptr);
+            KCHK();
+            e->prof.end(s);
+            continue;
+        }
+        for (int u0 = 0; u0 < B; u0 += chunk) {
+            const int bc = std::min(chunk, B - u0);
+            const size_t yo = (size_t)u0 * N * mel, to = (size_t)u0 * N * c.text_dim;
+            const long half_c = (long)bc * N * mel;
+            CHK(run_backbone<T>(e, w, w.y + yo, w.step_cond + yo, bc, use_cfg ? 2 * bc : bc, N, i, 0,
+                                lens_dev ? lens_dev + 2 * u0 : nullptr, 0, w.text_c + to,
+                                use_cfg ? w.text_u + to : w.text_c + to, s, fold_steps));
+            e->prof.begin(PC_MISC, s);
+            hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half_c / 4)), dim3(256), 0, s, w.y + yo, w.pred, half_c, w.tdev, i,
+                               cfg_strength, use_cfg ? 1 : 0,
+                               want_traj ? w.traj_buf + (size_t)(i + 1) * half + yo : nullptr);
+            KCHK();
+            e->prof.end(s);
+        }
     }
     // out = where(cond_mask, cond, y)   (cfm.py:221-223)
     e->prof.begin(PC_MISC, s);
@@ -1161,7 +1198,7 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     Work<T> w;
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     // ---- inputs -> arena (eager, on the caller's stream)
-    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s));
+    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, chunk_utts(e, B, N, !(cfg_strength < 1e-5f))));
     HIPCHK(hipMemcpyAsync(w.in_cond, cond, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(w.y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(w.in_mask, cond_mask, (size_t)B * N, hipMemcpyDeviceToDevice, s));
