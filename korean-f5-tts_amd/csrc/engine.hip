@@ -949,8 +949,10 @@ static int run_backbone(f5_engine* e, Work<T>& w, const float* y, const float* c
 // is stepped in chunks whose activations (x 4 B, xn, q, k, v, ffh 2 B per element: ~17 KB per row) stay inside the 256 MB
 // Infinity Cache between the kernels of a block, instead of streaming every intermediate through HBM (C3: 65,536 rows).
 // F5_CHUNK_ROWS overrides the row budget (tests force tiny chunks).
-static int chunk_utts(const f5_engine* e, int B, int N, bool use_cfg) {
-    static const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 20000;   // (C3: 4,096 / 8,192 / 16,384 / 32,768 / all rows -> 1.76 / 1.53 / 1.48 / 1.55 / 1.58 s)
+static bool split_cfg_enabled(f5_engine* e);
+static int chunk_utts(f5_engine* e, int B, int N, bool use_cfg) {
+    if (split_cfg_enabled(e)) return B;   // the opt-in two-stream mode steps the whole batch per half
+    const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 20000;   // (C3: 4,096 / 8,192 / 16,384 / 32,768 / all rows -> 1.76 / 1.53 / 1.48 / 1.55 / 1.58 s)
     const long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
     long bc = budget / rows_per_utt;
     if (bc < 1) bc = 1;
@@ -1210,7 +1212,8 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     unsigned cfg_bits;
     memcpy(&cfg_bits, &cfg_strength, 4);
     char kb[160];
-    snprintf(kb, sizeof(kb), "%d|%d|%d|%d|%08x|%d|%d", B, N, nt, steps, cfg_bits, lens_host ? 1 : 0, traj ? 1 : 0);
+    snprintf(kb, sizeof(kb), "%d|%d|%d|%d|%08x|%d|%d|%d", B, N, nt, steps, cfg_bits, lens_host ? 1 : 0, traj ? 1 : 0,
+             chunk_utts(e, B, N, use_cfg));
     const std::string base_key(kb);
     const std::string key = base_key + (uc_hit ? "|uc" : "|nouc");
     bool done = false;

@@ -165,6 +165,20 @@ def test_layernorm_fold_option_matches_default_path(monkeypatch):
     assert e1 < TOL_BF16 and e1 < 2.0 * e0 + 1e-3
 
 
+def test_chunked_batch_matches_reference_vectors(monkeypatch):
+    """sample() steps large batches in utterance chunks (engine.hip::chunk_utts).  F5_CHUNK_ROWS forces one utterance
+    per chunk on the three-utterance ragged fixture: the chunk-major length table, the per-chunk CFG halves and the
+    per-chunk Euler update must reproduce the reference exactly as the unchunked path does."""
+    monkeypatch.setenv("F5_CHUNK_ROWS", "150")   # 2 x 72 rows per utterance -> chunks of one
+    for name in ("sample_b3_masked", "sample_b3_attnmask", "sample_b2_v1arch", "sample_unett_b2"):
+        meta, a = load_golden(name)
+        sd = synthetic_weights(meta)
+        out, traj = run_case(meta, a, build_cfm(meta, sd, "f32"))
+        e = (traj.cpu() - a["traj"]).abs().max().item()
+        print(f"[chunked f32] {name}: traj Linf {e:.3e}")
+        assert e < TOL_PARITY and (out.cpu() - a["out"]).abs().max() < TOL_PARITY
+
+
 def test_full_size_properties():
     """BASELINE config C2 size (N=1024, NFE=16): size-independent properties instead of an oracle run."""
     arch = P.config.F5TTS_BASE
