@@ -17,7 +17,7 @@
 
 namespace f5 {
 
-template <typename T, int CPG>
+template <typename T, int CPG, int NS>
 __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ X, const T* __restrict__ Wp, int Kp,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       float* __restrict__ Y, int N, int D, const int* __restrict__ lens,
@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);    // k elements per weight tile (128 bytes)
     constexpr int EPC = 16 / sizeof(T);
     constexpr int NJ = CPG / 16;
-    constexpr int NS = 8;                             // weight ring stages
+    // NS = weight ring stages: 8 when the grid is one workgroup per CU (latency-bound, deep prefetch), 4 for large grids
+    // (55 KB of LDS: two workgroups per CU cover each other's prologue / epilogue)
     constexpr int WTILE = CPG * GEMM_ROW_BYTES;       // bytes of one weight K-tile (CPG rows x 128 B)
     constexpr int PIECES = CPG / 8;                   // 1 KiB LDS-DMA pieces per tile
     constexpr int L = PIECES >= 4 ? PIECES / 4 : 1;   // pieces per wave per tile (fewer pieces than waves: duplicates)
@@ -65,10 +66,10 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
             case 0: wait_vmcnt<0>(); break;
             case 1: wait_vmcnt<1 * L>(); break;
             case 2: wait_vmcnt<2 * L>(); break;
-            case 3: wait_vmcnt<3 * L>(); break;
-            case 4: wait_vmcnt<4 * L>(); break;
-            case 5: wait_vmcnt<5 * L>(); break;
-            default: wait_vmcnt<6 * L>(); break;
+            case 3: wait_vmcnt<(NS > 4 ? 3 : 2) * L>(); break;
+            case 4: wait_vmcnt<(NS > 4 ? 4 : 2) * L>(); break;
+            case 5: wait_vmcnt<(NS > 4 ? 5 : 2) * L>(); break;
+            default: wait_vmcnt<(NS > 4 ? 6 : 2) * L>(); break;
         }
     };
 #pragma unroll
@@ -141,22 +142,30 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     }
 }
 
-template <typename T, int CPG>
-inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
-                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
-    constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
-    if (Kp % KT != 0) return hipErrorInvalidValue;   // weights must be padded to whole K-tiles
-    constexpr int smem = 8 * CPG * GEMM_ROW_BYTES + (128 + 32) * (CPG * (int)sizeof(T) + 16);
+template <typename T, int CPG, int NS>
+inline hipError_t launch_convpos_ns(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
+                                    const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+    constexpr int smem = NS * CPG * GEMM_ROW_BYTES + (128 + 32) * (CPG * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((N + 127) / 128, D / CPG, Bp);
-    hipLaunchKernelGGL((convpos_kernel<T, CPG>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl);
+    hipLaunchKernelGGL((convpos_kernel<T, CPG, NS>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl);
     return hipGetLastError();
+}
+
+template <typename T, int CPG>
+inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
+                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+    constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
+    if (Kp % KT != 0) return hipErrorInvalidValue;   // weights must be padded to whole K-tiles
+    const long blocks = (long)((N + 127) / 128) * (D / CPG) * Bp;
+    if (blocks > 384) return launch_convpos_ns<T, CPG, 4>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+    return launch_convpos_ns<T, CPG, 8>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
 }
 
 // D/16 channels per group must be 16, 32 or 64 (dim 256 / 512 / 1024).

@@ -707,7 +707,8 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
-    static const bool wpf = !(getenv("F5_WEIGHT_PREFETCH") && getenv("F5_WEIGHT_PREFETCH")[0] == '0');   // see layernorm_kernel
+    // weight prefetch from the LayerNorm launches (see layernorm_kernel): only where the GEMMs are latency-bound
+    const bool wpf = rows <= 4096 && !(getenv("F5_WEIGHT_PREFETCH") && getenv("F5_WEIGHT_PREFETCH")[0] == '0');
     // AdaLayerNorm folded into the neighbouring GEMMs (lnfold.h): 5 launches per block instead of 7
     constexpr bool CAN_FOLD = std::is_same<T, bf16_t>::value;   // the exact-f32 precision keeps the reference's op order
     const bool fold = CAN_FOLD && fold_row != nullptr && mod_stride == 0;
