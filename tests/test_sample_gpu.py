@@ -272,3 +272,50 @@ def test_infer_process_end_to_end_vs_oracle():
     e_wav = float((torch.from_numpy(wave) - wref[0]).abs().max())
     print(f"[harness e2e f32] mel Linf {e_mel:.3e}, wav Linf {e_wav:.3e}")
     assert e_mel < 1e-3 and e_wav < 1e-3
+
+
+def _real_prompt():
+    """2 s (0.5 s .. 2.5 s) of the reference's bundled example prompt src/f5_tts/infer/examples/basic/basic_ref_en.wav
+    (24 kHz mono PCM16; its transcript is in basic.toml), stored as tests/golden/prompt_basic_ref_en_2s.wav: real speech
+    instead of white noise for the mel front-end (peaky spectrum, silence, 1e-5 clamp) and the harness numerics."""
+    import os
+    import wave
+
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prompt_basic_ref_en_2s.wav")
+    with wave.open(path) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 24000)
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    return torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]
+
+
+def test_real_speech_prompt_mel_and_harness():
+    from f5_tts_amd import infer as I
+
+    audio = _real_prompt()
+    ref = O.mel_spectrogram_vocos(audio)
+    got = P.mel.MelSpec()(audio.to(DEV)).cpu()
+    e = (got - ref).abs().max().item()
+    print(f"[mel front-end, real speech] frames {ref.shape[-1]}, log-mel range [{ref.min():.2f}, {ref.max():.2f}], Linf {e:.3e}")
+    assert got.shape == ref.shape and e < 2e-3
+    # the example's texts (basic.toml), through the harness: duration formula, byte tokens, prompt slicing, RMS handling
+    ref_text = "Some call me nature,"
+    gen_text = "I don't really care what you call me."
+    arch = P.config.F5TTS_TINY
+    tr = P.DiT(**arch, text_num_embeds=257, mel_dim=100, precision="f32").init_synthetic(seed=2)
+    model = P.CFM(transformer=tr).to(DEV)
+    vsd = P.weights.synthetic_state_dict(P.weights.vocos_param_shapes(P.config.VOCOS_TINY), seed=4)
+    voc = P.Vocos(P.config.VOCOS_TINY)
+    voc.load_state_dict(vsd)
+    voc.to(DEV)
+    kw = dict(nfe_step=5, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    wave_out, sr, spec = I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw)
+    a, rms, rtext, ref_len, dur = I.prompt_numerics(audio, 24000, ref_text, gen_text)
+    cond = O.mel_spectrogram_vocos(a).permute(0, 2, 1)
+    text = P.utils.list_str_to_tensor([rtext + gen_text])
+    out, _ = O.sample(tr.state_dict(), arch, cond, text, dur, steps=5, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    wref = O.vocos_decode(vsd, out[:, ref_len:].permute(0, 2, 1)) * (rms / 0.1 if rms < 0.1 else 1.0)
+    e_mel = float((torch.from_numpy(spec) - out[0, ref_len:].t()).abs().max())
+    e_wav = float((torch.from_numpy(wave_out) - wref[0]).abs().max())
+    print(f"[harness e2e f32, real prompt] rms {rms:.4f}, prompt {ref_len} frames, total {dur}; mel Linf {e_mel:.3e}, wav Linf {e_wav:.3e}")
+    assert wave_out.shape == (wref.shape[-1],) and e_mel < 1e-3 and e_wav < 1e-3
