@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="Euler steps timed on the host for cpu_baseline")
     ap.add_argument("--setup-runs", type=int, default=3, help="untimed engine-initialisation runs before the warm-up")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the collectives run on gloo "
+                         "through host copies (RCCL refuses two ranks on one device); never used for reported numbers")
     return ap.parse_args()
 
 
@@ -122,11 +125,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import f5_tts_amd as P
 
@@ -163,7 +171,12 @@ def main():
         else:  # per item, as the reference's harness does (eval_infer_batch.py:202-206): own prompt / total length
             wav = [voc.decode(out[i:i + 1, refs[i]:durs[i], :].permute(0, 2, 1)) for i in range(B)][-1]
         if world > 1:
-            dist.all_gather_into_tensor(gather_buf, out.contiguous())
+            if args.rehearse_one_gpu:   # gloo has no device collectives: same call shape on host copies
+                host = torch.empty(gather_buf.shape, dtype=gather_buf.dtype)
+                dist.all_gather_into_tensor(host, out.contiguous().cpu())
+                gather_buf.copy_(host)
+            else:
+                dist.all_gather_into_tensor(gather_buf, out.contiguous())
         return out, wav
 
     def barrier():
@@ -186,7 +199,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all() and torch.isfinite(wav).all()
