@@ -13,6 +13,7 @@
 #pragma once
 #include "gemm.h"
 
+
 namespace f5 {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -167,7 +168,11 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // cannot afford the registers (the 256x128 tile spilled): they set the epilogue up after the loop.
     float* rowlds = reinterpret_cast<float*>(smem + NS * STAGE);   // (only used when Epi::kRowLdsFloats > 0)
     constexpr int PRE_WORDS = sizeof(typename Epi::Pre) >= 4 ? (int)sizeof(typename Epi::Pre) / 4 : 0;
-    constexpr bool EARLY = MI * NJ * (1 + PRE_WORDS) <= 64 && !(Epi::kRowLdsFloats > 0 && MI * NJ >= 12);   // (lnfold.h contexts are wider: 128x192 spilled)
+    // (measured, normalised by the attention kernel of the same run: early setup helps the residual GEMMs ~2 %, is
+    // neutral for FF1 and costs the 128x192 QKV tile ~3 % -- 230 VGPRs live across the loop -- so big transposing tiles
+    // set up late)
+    constexpr bool EARLY = MI * NJ * (1 + PRE_WORDS) <= 64 && !(Epi::kRowLdsFloats > 0 && MI * NJ >= 12) &&
+                           !(Epi::kTransposes && MI * NJ >= 12);   // (lnfold.h contexts are wider: 128x192 spilled)
     const int mw = m0 + wr * TM, nw = n0 + wc * TN;
     bool any_row = false, any_tr = false;
 #pragma unroll
