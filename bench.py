@@ -120,6 +120,13 @@ def main():
         args.batch, args.nfe = (32 if args.batch == 1 else args.batch), (32 if args.nfe == 16 else args.nfe)
     if args.workload == "c5":
         args.batch = 8 if args.batch == 1 else args.batch
+    # The GPU path has no parallel host work, and torch's default intra-op pool is one thread per LOGICAL CPU of the
+    # host (256 on the GPU boxes, of which a job owns a 16-CPU share; x8 ranks on a node): every tiny CPU op of a step
+    # (noise draw, pads) then wakes an oversubscribed OpenMP team whose spinning starves the HIP submission thread.
+    # Measured on a loaded box (tools/stall_probe.py): p90 / max per utterance 99.9 / 198.7 ms with the default pool,
+    # 33.9 / 37.3 ms with one thread (median 33-36 ms either way).  cpu_baseline() sets its own thread count later.
+    P_threads = int(os.environ.get("F5_HOST_THREADS", "1"))
+    torch.set_num_threads(P_threads)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

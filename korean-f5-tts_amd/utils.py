@@ -55,3 +55,14 @@ def load_vocab(path: str) -> tuple[dict[str, int], int]:
         for i, ch in enumerate(f):
             m[ch[:-1]] = i
     return m, len(m)
+
+
+def configure_host_threads(n: int = 1) -> None:
+    """The engine's host side is a handful of tiny CPU tensor ops per call (seeded noise draw, pads, masks).  torch's default
+    intra-op pool has one thread per logical CPU of the HOST, not of the job's share, so on a shared or multi-rank node
+    those ops wake an oversubscribed OpenMP team and its spinning workers starve the HIP runtime's submission thread:
+    occasional 100-200 ms utterances instead of 34 ms (tools/stall_probe.py).  Serving loops should call this once."""
+    import torch
+
+    torch.set_num_threads(n)
+
