@@ -45,6 +45,10 @@ def dp_sample(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durat
     Returns (mels, lens): mels f32[n_utt, N_max, mel] in the original order (zero padded), lens list[int].
     Exactly one collective: all_gather_into_tensor of a [per_rank_max, N_max, mel] buffer.
     """
+    import os
+
+    from .utils import configure_host_threads
+    configure_host_threads(int(os.environ.get("F5_HOST_THREADS", "1")))   # one rank per GPU shares the host: see utils.py
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     shards = partition(durations, world)
