@@ -1079,9 +1079,8 @@ template <typename T> static Work<T> second_half(const f5_engine* e, const Work<
 static bool split_cfg_enabled(f5_engine* e) {
     if (e->split_cfg < 0) {
         const char* v = getenv("F5_SPLIT_CFG");
-        e->split_cfg = (v && v[0] == '1') ? 1 : 0;   // opt-in: measured 43.2 ms eager vs 45.9 packed, but 57.9 ms when
-                                                     // replayed as a two-branch hipGraph (ROCm 7.2), so packed + graph
-                                                     // stays the default
+        e->split_cfg = (v && v[0] == '1') ? 1 : 0;   // opt-in: 35.4 ms as two eager chains, 35.2 ms as a two-branch
+                                                     // hipGraph, against 34.4 ms packed
     }
     return e->split_cfg == 1;
 }
