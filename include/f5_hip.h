@@ -32,6 +32,8 @@ extern "C" {
 
 #define F5_PREC_F32 0    /* exact-f32 MFMA everywhere ("parity" mode) */
 #define F5_PREC_BF16 1   /* bf16 MFMA operands, f32 accumulate, f32 residual stream / ODE state / norms */
+#define F5_PREC_F16 2    /* fp16 MFMA operands (the reference's own GPU dtype, infer/utils_infer.py:243-251; same MFMA rate as
+                            bf16, 3 more mantissa bits), f32 accumulate, f32 residual stream / ODE state / norms */
 
 #define F5_BACKBONE_DIT 0
 #define F5_BACKBONE_UNETT 1
@@ -44,7 +46,7 @@ typedef void* f5_stream; /* hipStream_t */
 typedef struct f5_config {
     int32_t backbone;          /* F5_BACKBONE_* */
     int32_t precision;         /* F5_PREC_* */
-    int32_t dim;               /* model width D (multiple of 256: 256, 512, 1024) */
+    int32_t dim;               /* model width D: 256, 512, 768 or 1024 */
     int32_t depth;
     int32_t heads;
     int32_t dim_head;          /* must be 64 */

@@ -151,10 +151,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
                 u32x4 pf[2];
 #pragma unroll
                 for (int qs = 0; qs < 2; ++qs) {
-                    bf16x8 pv = {(bf16_t)s[2 * kp][qs][0],     (bf16_t)s[2 * kp][qs][1],     (bf16_t)s[2 * kp][qs][2],
-                                 (bf16_t)s[2 * kp][qs][3],     (bf16_t)s[2 * kp + 1][qs][0], (bf16_t)s[2 * kp + 1][qs][1],
-                                 (bf16_t)s[2 * kp + 1][qs][2], (bf16_t)s[2 * kp + 1][qs][3]};
-                    pf[qs] = __builtin_bit_cast(u32x4, pv);
+                    pf[qs] = pack8<T>(s[2 * kp][qs][0], s[2 * kp][qs][1], s[2 * kp][qs][2], s[2 * kp][qs][3],
+                                      s[2 * kp + 1][qs][0], s[2 * kp + 1][qs][1], s[2 * kp + 1][qs][2], s[2 * kp + 1][qs][3]);
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {

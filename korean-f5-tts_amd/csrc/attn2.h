@@ -16,7 +16,7 @@
 //   LDS image: K tile [64 keys][128 B], 16-byte chunk c of row r in slot c ^ kswz(r); V^T tile [64 dh][128 B], slot
 //   c ^ (r & 7); both make every ds_read_b128 fragment read conflict-free.  The swizzle is applied to the per-lane
 //   SOURCE address of the LDS-DMA (the LDS side of a global_load_lds is lane-linear).
-// bf16 operands only (the exact-f32 precision keeps attn.h's kernel).
+// 16-bit operands (T = bf16_t or f16_t); the exact-f32 precision keeps attn.h's kernel.
 #pragma once
 #include "attn.h"
 #include "gemm2.h"
@@ -38,7 +38,7 @@ __device__ __forceinline__ float group_max(float v) {
 // One KV tile for one wave.  STAGE and EDGE are compile-time so that LDS addresses fold into instruction offsets and the
 // key-padding mask costs nothing on interior tiles.  All eight fragment reads of the tile (4 K, 4 V^T) are issued
 // up front as asm ds_reads with hand-counted lgkmcnt waits (gemm2.h explains why).
-template <int STAGE_IDX, bool EDGE, int VAR>
+template <typename T, int STAGE_IDX, bool EDGE, int VAR>
 __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_base, int k_off, int kc0, int kc1, int v_off, int vc,
                                            const u32x4 (&qf)[2][2], f32x4 (&o)[4][2], float (&mrun)[2], float (&lrun)[2],
                                            int key_base, int kv_len, bool first) {
@@ -78,7 +78,7 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[0][ks], qf[qs][0], s[ks][qs]);
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<T>::run(kf[0][ks], qf[qs][0], s[ks][qs]);
     if (VAR & 1) {
         __builtin_amdgcn_sched_barrier(0);
         wait_lgkm<4>(kf[1][0], kf[1][1]);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<bf16_t>::run(kf[1][ks], qf[qs][1], s[ks][qs]);
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = Mma<T>::run(kf[1][ks], qf[qs][1], s[ks][qs]);
     // ---- online softmax over this wave's keys (lane group g owns keys key_base + 4 ks + r)
     if (LAZY) {
         // Softmax is shift-invariant: any per-query reference c works as long as 2^(s - c) stays in range.  c follows the
@@ -206,9 +206,7 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
     u32x4 pf2[2];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
-        bf16x8 pv = {(bf16_t)s[0][qs][0], (bf16_t)s[0][qs][1], (bf16_t)s[0][qs][2], (bf16_t)s[0][qs][3],
-                     (bf16_t)s[1][qs][0], (bf16_t)s[1][qs][1], (bf16_t)s[1][qs][2], (bf16_t)s[1][qs][3]};
-        pf2[qs] = __builtin_bit_cast(u32x4, pv);
+        pf2[qs] = pack8<T>(s[0][qs][0], s[0][qs][1], s[0][qs][2], s[0][qs][3], s[1][qs][0], s[1][qs][1], s[1][qs][2], s[1][qs][3]);
     }
     if (VAR & 1) {
         __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +215,7 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<bf16_t>::run(vf[dt], pf2[qs], o[dt][qs]);
+        for (int qs = 0; qs < 2; ++qs) o[dt][qs] = Mma<T>::run(vf[dt], pf2[qs], o[dt][qs]);
     }
 }
 
@@ -225,9 +223,9 @@ __device__ __forceinline__ void attn2_tile(const char* smem_ptr, unsigned lds_ba
 // rows {8a + 4ks + b}; kswz makes those land on 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int kswz(int r) { return (((r >> 3) & 3) << 1) | ((r >> 1) & 1); }
 
-template <int VAR>
-__global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                               const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int H,
+template <typename T, int VAR>
+__global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
+                                                               const T* __restrict__ Vt, T* __restrict__ O, int H,
                                                                int N, int Npad, const int* __restrict__ kv_lens,
                                                                int nbatch_lens) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -267,8 +265,8 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
     const int kchunk = ls ^ kswz(krow);
     const int vrow = wave * 8 + lr;                       // dh row
     const int vchunk = ls ^ (vrow & 7);
-    const bf16_t* ksrc = K + bh * (size_t)N * 64 + kchunk * 8;
-    const bf16_t* vsrc = Vt + (bh * 64 + vrow) * (size_t)Npad + vchunk * 8;
+    const T* ksrc = K + bh * (size_t)N * 64 + kchunk * 8;
+    const T* vsrc = Vt + (bh * 64 + vrow) * (size_t)Npad + vchunk * 8;
     auto issue = [&](int kt, int stage) {
         if (kt >= nkt) return;   // nothing past the last tile: no dummy load to wait for at the end
         const int t = kt;
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
         if (kt + 1 < nkt) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();                                            \
         __builtin_amdgcn_s_barrier();                                                                                  \
         issue(kt + NS - 1, (SI + NS - 1) % NS);                                                                        \
-        attn2_tile<SI, EDGE_, VAR>(smem, lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len, kt == 0);        \
+        attn2_tile<T, SI, EDGE_, VAR>(smem, lds_base, k_off, kc0, kc1, v_off, vc, qf, o, mrun, lrun, kt * 64 + key_lane, kv_len, kt == 0);        \
         ++kt;                                                                                                          \
     }
     while (kt + 3 <= nfull) {
@@ -353,7 +351,7 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const bf16_t* __restrict
             const float inv = 1.0f / (lrun[qs] * a0 + l1 * a1);
             const int q = q0 + qs * 16 + l15;
             if (q < N) {
-                bf16_t* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
+                T* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     float v[4];
@@ -373,8 +371,10 @@ inline int& attn2_variant() { static int v = 7; return v; }
 template <typename T> inline float attention_q_scale();   // dim_head^-0.5 (x log2 e where the kernel works in log2 units)
 template <> inline float attention_q_scale<float>() { return 0.125f; }
 template <> inline float attention_q_scale<bf16_t>() { return (attn2_variant() & 4) ? 0.125f * 1.4426950408889634f : 0.125f; }
-inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp, int H,
-                                    int N, int Npad, const int* kv_lens, int nbatch_lens) {
+template <> inline float attention_q_scale<f16_t>() { return attention_q_scale<bf16_t>(); }
+template <typename T>
+inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H,
+                                      int N, int Npad, const int* kv_lens, int nbatch_lens) {
     constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
     dim3 grid(Bp * H, (N + 127) / 128);
     const int var = attn2_variant();
@@ -382,12 +382,12 @@ inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const
     {                                                                                                                  \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<V>),                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<T, V>),                    \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);                      \
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL(attn2_fwd_kernel<V>, grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens); \
+        hipLaunchKernelGGL((attn2_fwd_kernel<T, V>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens); \
     }
     if (var == 0) F5_ATTN2_LAUNCH(0)
     else if (var == 3) F5_ATTN2_LAUNCH(3)
@@ -396,10 +396,14 @@ inline hipError_t launch_attention_bf16_v2(hipStream_t s, const bf16_t* Q, const
     return hipGetLastError();
 }
 
-// precision dispatch: bf16 -> v2 (this file), f32 -> attn.h
+// precision dispatch: bf16 / f16 -> v2 (this file), f32 -> attn.h
 inline hipError_t launch_attention_any(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp,
                                        int H, int N, int Npad, const int* kv_lens, int nbl) {
-    return launch_attention_bf16_v2(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl);
+    return launch_attention_v2<bf16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl);
+}
+inline hipError_t launch_attention_any(hipStream_t s, const f16_t* Q, const f16_t* K, const f16_t* Vt, f16_t* O, int Bp,
+                                       int H, int N, int Npad, const int* kv_lens, int nbl) {
+    return launch_attention_v2<f16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H,
                                        int N, int Npad, const int* kv_lens, int nbl) {

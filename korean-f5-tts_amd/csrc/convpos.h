@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     // (55 KB of LDS: two workgroups per CU cover each other's prologue / epilogue)
     constexpr int WTILE = CPG * GEMM_ROW_BYTES;       // bytes of one weight K-tile (CPG rows x 128 B)
     constexpr int PIECES = CPG / 8;                   // 1 KiB LDS-DMA pieces per tile
-    constexpr int L = PIECES >= 4 ? PIECES / 4 : 1;   // pieces per wave per tile (fewer pieces than waves: duplicates)
+    constexpr int L = (PIECES + 3) / 4;               // pieces per wave per tile (pieces % 4 != 0: some are staged twice, same bytes)
     char* ws = smem;                                  // ring first: 1 KiB-aligned DMA destinations
     char* xs = smem + NS * WTILE;
 
@@ -168,13 +168,14 @@ inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp,
     return launch_convpos_ns<T, CPG, 8>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
 }
 
-// D/16 channels per group must be 16, 32 or 64 (dim 256 / 512 / 1024).
+// D/16 channels per group must be 16, 32, 48 or 64 (dim 256 / 512 / 768 / 1024).
 template <typename T>
 inline hipError_t launch_convpos(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias, const float* res,
                                  float* Y, int Bp, int N, int D, const int* lens, int nbl) {
     switch (D / 16) {
         case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
         case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+        case 48: return launch_convpos_cpg<T, 48>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
         case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
         default: return hipErrorInvalidValue;
     }

@@ -1,5 +1,5 @@
 // Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the F5-TTS engine.
-// Wave = 64 lanes everywhere; MFMA tiles are 16x16 (bf16: 16x16x32, f32: 16x16x4).
+// Wave = 64 lanes everywhere; MFMA tiles are 16x16 (bf16 / f16: 16x16x32, f32: 16x16x4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,13 +8,16 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define F5_WAVE 64
 
-// (operand precision ids F5_PREC_F32 / F5_PREC_BF16 live in include/f5_hip.h)
+// (operand precision ids F5_PREC_F32 / F5_PREC_BF16 / F5_PREC_F16 live in include/f5_hip.h)
 // activation ids used by GEMM epilogues
 enum { F5_ACT_NONE = 0, F5_ACT_GELU_TANH = 1, F5_ACT_GELU_ERF = 2, F5_ACT_SILU = 3, F5_ACT_MISH = 4, F5_ACT_LOGCLAMP = 5 };
 
@@ -51,6 +54,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -58,6 +62,21 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
     bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
     *reinterpret_cast<bf16x4*>(p) = v;
+}
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+    f16x4 v = {(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
+    *reinterpret_cast<f16x4*>(p) = v;
+}
+
+// eight f32 -> one 16-byte MFMA operand fragment of 16-bit type T
+template <typename T> __device__ __forceinline__ u32x4 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7);
+template <> __device__ __forceinline__ u32x4 pack8<bf16_t>(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    bf16x8 v = {(bf16_t)a0, (bf16_t)a1, (bf16_t)a2, (bf16_t)a3, (bf16_t)a4, (bf16_t)a5, (bf16_t)a6, (bf16_t)a7};
+    return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 pack8<f16_t>(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    f16x8 v = {(f16_t)a0, (f16_t)a1, (f16_t)a2, (f16_t)a3, (f16_t)a4, (f16_t)a5, (f16_t)a6, (f16_t)a7};
+    return __builtin_bit_cast(u32x4, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

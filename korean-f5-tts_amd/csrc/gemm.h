@@ -2,7 +2,7 @@
 //
 // Both operands are K-contiguous (activations [rows, features]; torch nn.Linear weights [out, in]), so a 16-byte
 // chunk of either is directly one MFMA operand fragment:
-//   bf16: v_mfma_f32_16x16x32_bf16 -- lane l holds row (l&15), k = 8*(l>>4)..+7            (one fragment = 1 MFMA)
+//   bf16 / f16: v_mfma_f32_16x16x32_{bf16,f16} -- lane l holds row (l&15), k = 8*(l>>4)..+7 (one fragment = 1 MFMA)
 //   f32 : v_mfma_f32_16x16x4_f32   -- lane l holds row (l&15), 4 consecutive k of chunk (l>>4); element j feeds the
 //         j-th of 4 MFMAs (the k order inside a 16-wide group is permuted identically for both operands, which a sum
 //         over k does not care about).  Exact f32: bit-for-bit an fmaf chain (MI355X_MICROARCH "Matrix cores").
@@ -29,6 +29,11 @@ template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                        0, 0, 0);
+    }
+};
+template <> struct Mma<f16_t> {   // v_mfma_f32_16x16x32_f16: same fragment layout and rate as the bf16 form, 10-bit mantissa operands
+    static __device__ __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -64,8 +69,6 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
     static constexpr bool kTransposes = false;
-    static constexpr int kRowLdsFloats = 0;    // per-row floats the workgroup stages in LDS before the K loop (lnfold.h)
-    static constexpr bool kRowDone = false;    // row_done() hook after the stores (lnfold.h)
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const { return {out + (size_t)m * ldo}; }
     __device__ __forceinline__ ColCtx col(int n) const {
@@ -108,8 +111,6 @@ struct EpiGateRes {
     typedef NoCtx TRowCtx;
     typedef NoCtx TColCtx;
     static constexpr bool kTransposes = false;
-    static constexpr int kRowLdsFloats = 0;    // per-row floats the workgroup stages in LDS before the K loop (lnfold.h)
-    static constexpr bool kRowDone = false;    // row_done() hook after the stores (lnfold.h)
     __device__ __forceinline__ bool tile_transposed(int) const { return false; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / rows_per_batch;
@@ -150,8 +151,6 @@ template <typename TO> struct EpiQKV {
     struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
     struct TColCtx { float b; size_t hoff; };
     static constexpr bool kTransposes = true;
-    static constexpr int kRowLdsFloats = 0;
-    static constexpr bool kRowDone = false;
     __device__ __forceinline__ bool tile_transposed(int n0) const { return n0 >= 2 * H * 64; }
     __device__ __forceinline__ RowCtx row(int m) const {
         const int b = m / Nseq, pos = m - b * Nseq;

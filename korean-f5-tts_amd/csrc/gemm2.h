@@ -166,13 +166,11 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // here, before the first tile: their latency hides under the K loop instead of adding a round trip after it.  They
     // are older than every LDS-DMA piece, so the counted vmcnt waits of the loop retire them first.  Large wave tiles
     // cannot afford the registers (the 256x128 tile spilled): they set the epilogue up after the loop.
-    float* rowlds = reinterpret_cast<float*>(smem + NS * STAGE);   // (only used when Epi::kRowLdsFloats > 0)
     constexpr int PRE_WORDS = sizeof(typename Epi::Pre) >= 4 ? (int)sizeof(typename Epi::Pre) / 4 : 0;
     // (measured, normalised by the attention kernel of the same run: early setup helps the residual GEMMs ~2 %, is
     // neutral for FF1 and costs the 128x192 QKV tile ~3 % -- 230 VGPRs live across the loop -- so big transposing tiles
     // set up late)
-    constexpr bool EARLY = MI * NJ * (1 + PRE_WORDS) <= 64 && !(Epi::kRowLdsFloats > 0 && MI * NJ >= 12) &&
-                           !(Epi::kTransposes && MI * NJ >= 12);   // (lnfold.h contexts are wider: 128x192 spilled)
+    constexpr bool EARLY = MI * NJ * (1 + PRE_WORDS) <= 64 && !(Epi::kTransposes && MI * NJ >= 12);
     const int mw = m0 + wr * TM, nw = n0 + wc * TN;
     bool any_row = false, any_tr = false;
 #pragma unroll
@@ -187,8 +185,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = min(mw + i * 16 + l15, M - 1);
-                if constexpr (Epi::kRowLdsFloats > 0) rc[i] = epi.row_lds(m, rowlds + (m - m0) * Epi::kRowLdsFloats);
-                else rc[i] = epi.row(m);
+                rc[i] = epi.row(m);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -201,19 +198,14 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = min(mw + i * 16 + g * 4, M - 1);
-                if constexpr (Epi::kRowLdsFloats > 0) trc[i] = epi.trow_lds(m, M, rowlds + (m - m0) * Epi::kRowLdsFloats, 4);
-                else trc[i] = epi.trow(m, M);
+                trc[i] = epi.trow(m, M);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) tcc[j] = epi.tcol(min(nw + j * 16 + l15, N - 1));
         }
     };
-    // per-row operands an epilogue wants reduced once per workgroup (lnfold.h: LayerNorm statistics of the stripe) are
-    // requested first (oldest loads), then the first tiles, then the epilogue's own operands
-    if constexpr (Epi::kRowLdsFloats > 0) epi.block_prologue(rowlds, m0, BM, M, tid, NW * 64);
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t, t);
-    if constexpr (Epi::kRowLdsFloats > 0) __syncthreads();
     if (EARLY) epilogue_setup();
 
     // retire every scalar/LDS operation of the prologue: with nothing of another kind pending on the lgkm counter the
@@ -322,10 +314,6 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
                 if (mw + i * 16 + g * 4 < M) epi.tstore(trc[i], tcc[j], acc[i][j]);
         }
     }
-    if constexpr (Epi::kRowDone) {   // (all lanes: the hook reduces across the lane groups of a row)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) epi.row_done(rc[i], nw / 16, mw + i * 16 + l15 < M);
-    }
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
@@ -362,7 +350,7 @@ inline void pick_xcd_rect(int tiles_m, int tiles_n, int* xa, int* xb) {
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                    const Epi& epi) {
-    constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES + (Epi::kRowLdsFloats > 0 ? (BM + 4) * Epi::kRowLdsFloats * 4 : 0);
+    constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>),

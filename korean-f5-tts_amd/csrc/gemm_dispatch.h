@@ -48,17 +48,7 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     if (M <= 0 || N <= 0) return hipSuccess;
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
     if (K % KT == 0 && force_cfg != -2) return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, force_cfg >= 0 ? force_cfg : pick_cfg_v2(M, N));
-    if constexpr (Epi::kRowLdsFloats > 0 || Epi::kRowDone) return hipErrorInvalidValue;   // lnfold.h epilogues need the v2 kernel
-    else return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
-}
-
-// wave-tile width (columns) of a configuration: the granularity of the row partial sums an EpiGateResLN launch writes
-inline int gemm_cfg_wave_cols(int cfg) {
-    switch (cfg) {
-        case G2_256x128_8W: return 64;
-        case G2_128x192_8W: return 48;
-        default: return 32;
-    }
+    return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }
 
 }  // namespace f5

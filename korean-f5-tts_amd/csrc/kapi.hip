@@ -11,6 +11,9 @@
 
 using namespace f5;
 #define fail f5_fail
+// precision dispatch of a function template call FN<T>(args...)
+#define F5K_BY_PREC(prec, FN, ...) \
+    ((prec) == F5_PREC_BF16 ? FN<bf16_t>(__VA_ARGS__) : (prec) == F5_PREC_F16 ? FN<f16_t>(__VA_ARGS__) : FN<float>(__VA_ARGS__))
 
 template <typename T>
 static int gemm_impl(const float* A, const float* W, const float* bias, int act, float* out, int M, int N, int K, int tm,
@@ -34,8 +37,7 @@ extern "C" int f5k_gemm(int32_t prec, const float* A, const float* W, const floa
     if (tm > 0 && !((tm == 128 && (tn == 128 || tn == 64)) || (tm == 64 && tn == 64))) return fail(F5_EINVAL, "f5k_gemm: bad tile");
     if (tm < 0 && tm != -2 && tm != -8 && tm != -9) return fail(F5_EINVAL, "f5k_gemm: bad v2 config id");
     hipStream_t s = (hipStream_t)stream;
-    return prec == F5_PREC_BF16 ? gemm_impl<bf16_t>(A, W, bias, act, out, M, N, K, tm, tn, s)
-                                : gemm_impl<float>(A, W, bias, act, out, M, N, K, tm, tn, s);
+    return F5K_BY_PREC(prec, gemm_impl, A, W, bias, act, out, M, N, K, tm, tn, s);
 }
 
 template <typename T>
@@ -83,8 +85,7 @@ extern "C" int f5k_gemm_time(int32_t prec, int32_t M, int32_t N, int32_t K, int3
                              float* avg_us, f5_stream stream) {
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (N % 4)) return fail(F5_EINVAL, "f5k_gemm_time: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    return prec == F5_PREC_BF16 ? gemm_time_impl<bf16_t>(M, N, K, tm, tn, iters, avg_us, s)
-                                : gemm_time_impl<float>(M, N, K, tm, tn, iters, avg_us, s);
+    return F5K_BY_PREC(prec, gemm_time_impl, M, N, K, tm, tn, iters, avg_us, s);
 }
 
 // packs fp32 [Bp,H,N,64] q/k/v into the engine layouts (q scaled, v transposed) -- test-side glue only
@@ -136,8 +137,7 @@ extern "C" int f5k_attention(int32_t prec, const float* q, const float* k, const
                              float* out, int32_t Bp, int32_t H, int32_t N, f5_stream stream) {
     if (!q || !k || !v || !out || Bp <= 0 || H <= 0 || N <= 0) return fail(F5_EINVAL, "f5k_attention: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    return prec == F5_PREC_BF16 ? attn_impl<bf16_t>(q, k, v, kv_lens_host, out, Bp, H, N, s)
-                                : attn_impl<float>(q, k, v, kv_lens_host, out, Bp, H, N, s);
+    return F5K_BY_PREC(prec, attn_impl, q, k, v, kv_lens_host, out, Bp, H, N, s);
 }
 
 template <typename T>
@@ -161,10 +161,9 @@ static int convpos_impl(const float* x, const float* w, const float* bias, const
 extern "C" int f5k_convpos(int32_t prec, const float* x, const float* w, const float* bias, const float* res,
                            const int32_t* lens_host, float* y, int32_t Bp, int32_t N, int32_t D, f5_stream stream) {
     if (!x || !w || !bias || !y || Bp <= 0 || N <= 0) return fail(F5_EINVAL, "f5k_convpos: bad arguments");
-    if (D != 256 && D != 512 && D != 1024) return fail(F5_EINVAL, "f5k_convpos: D must be 256, 512 or 1024");
+    if (D != 256 && D != 512 && D != 768 && D != 1024) return fail(F5_EINVAL, "f5k_convpos: D must be 256, 512, 768 or 1024");
     hipStream_t s = (hipStream_t)stream;
-    return prec == F5_PREC_BF16 ? convpos_impl<bf16_t>(x, w, bias, res, lens_host, y, Bp, N, D, s)
-                                : convpos_impl<float>(x, w, bias, res, lens_host, y, Bp, N, D, s);
+    return F5K_BY_PREC(prec, convpos_impl, x, w, bias, res, lens_host, y, Bp, N, D, s);
 }
 
 extern "C" int f5k_layernorm_mod(const float* x, const float* scale, const float* shift, float* out, int32_t R, int32_t D,
@@ -270,8 +269,7 @@ extern "C" int f5x_gemm2(int32_t prec, const float* A, const float* W, const flo
                          int32_t N, int32_t K, int32_t cfg, int32_t iters, float* avg_us, f5_stream stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % 4)) return fail(F5_EINVAL, "f5x_gemm2: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    return prec == F5_PREC_BF16 ? gemm2_impl<bf16_t>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s)
-                                : gemm2_impl<float>(A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s);
+    return F5K_BY_PREC(prec, gemm2_impl, A, W, bias, act, out, M, N, K, cfg, iters, avg_us, s);
 }
 
 

@@ -70,7 +70,7 @@ class Engine:
         self.max_pos = max_pos
         cfg = _lib.f5_config()
         cfg.backbone = _lib.F5_BACKBONE_DIT if backbone == "DiT" else _lib.F5_BACKBONE_UNETT
-        cfg.precision = {"f32": _lib.F5_PREC_F32, "fp32": _lib.F5_PREC_F32, "bf16": _lib.F5_PREC_BF16}[precision]
+        cfg.precision = _lib.PRECISIONS[precision]
         cfg.dim, cfg.depth, cfg.heads, cfg.dim_head = a["dim"], a["depth"], a["heads"], a["dim_head"]
         cfg.ff_dim = int(a["dim"] * a["ff_mult"])
         cfg.text_dim, cfg.conv_layers = a["text_dim"], a["conv_layers"]

@@ -17,7 +17,7 @@ def _s():
 
 
 def prec_id(name):
-    return _lib.F5_PREC_BF16 if name == "bf16" else _lib.F5_PREC_F32
+    return _lib.PRECISIONS[name]
 
 
 def k_gemm(prec, A, W, bias=None, act=0, tile=(0, 0)):

@@ -1,5 +1,8 @@
 """GPU: every hand-written kernel against a torch fp32 restatement of the same op (through the C ABI's f5k_* entry
-points).  f32 mode must agree to fp32 rounding; bf16 mode to bf16 operand rounding (tolerances written per test)."""
+points).  f32 mode must agree to fp32 rounding.  The 16-bit-operand modes (bf16, f16) are checked twice: against the
+plain fp32 op at the operand type's rounding, and -- tightly -- against the same op evaluated in float64 on operands
+ROUNDED to that type, which leaves only the kernel's own arithmetic (f32 accumulation, P rounded to 16 bit inside the
+attention kernel): a 2x accuracy regression in a speed path fails these (tolerances written per test)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -13,12 +16,20 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+TDTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def rnd(prec, x):
+    """x as the kernel's MFMA operand type sees it (f32: unchanged)."""
+    return x if prec == "f32" else x.to(TDTYPE[prec]).float()
+
+
 GEMM_SHAPES = [(2048, 1024, 1024), (2048, 3072, 1024), (2048, 1024, 2048), (300, 100, 1024), (77, 64, 712),
                (16, 6144, 1024), (1, 4, 8), (130, 260, 40), (513, 1028, 512)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 1.5e-2), ("f16", 2e-3)])
 def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).to(DEV)
@@ -28,10 +39,13 @@ def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     out = k_gemm(prec, A, W, b)
     assert torch.isfinite(out).all()
     assert rel_err(out, ref) < tol
+    # same operands as the kernel multiplies: only the f32 accumulation order is left
+    ref_r = F.linear(rnd(prec, A).double(), rnd(prec, W).double(), b.double()).float()
+    assert rel_err(out, ref_r) < 2e-5
 
 
 @pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64), (-2, 0), (-8, 0), (-9, 0)])  # v1 tiles, v2 config ids
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_gemm_every_tile_shape_and_identity(tile, prec):
     """A = I with an ASYMMETRIC W catches a transposed accumulator map (guide section 3)."""
     M = N = K = 256
@@ -62,18 +76,26 @@ def sdpa_ref(q, k, v, lens=None):
     return o.transpose(1, 2).reshape(q.shape[0], q.shape[2], -1).float()
 
 
+# tol: against SDPA of the unrounded operands; tol_r: against SDPA of the operands as the kernel rounds them (what is
+# left is the 16-bit rounding of P inside the kernel and f32 accumulation)
+ATTN_TOLS = [("f32", 3e-5, 3e-5), ("bf16", 2e-2, 6e-3), ("f16", 3e-3, 8e-4)]
+
+
 @pytest.mark.parametrize("Bp,H,N", [(2, 16, 1024), (1, 4, 64), (2, 4, 48), (3, 2, 200), (1, 2, 129), (2, 3, 777)])
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
-def test_attention_matches_sdpa(Bp, H, N, prec, tol):
+@pytest.mark.parametrize("prec,tol,tol_r", ATTN_TOLS)
+def test_attention_matches_sdpa(Bp, H, N, prec, tol, tol_r):
     g = torch.Generator().manual_seed(N)
     q, k, v = (torch.randn(Bp, H, N, 64, generator=g).to(DEV) for _ in range(3))
     out = k_attention(prec, q, k, v)
     ref = sdpa_ref(q, k, v)
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max() < tol
+    e_r = (out - sdpa_ref(*_as_operands(prec, q, k, v))).abs().max().item()
+    print(f"[attention {prec}] Bp={Bp} H={H} N={N}: Linf vs SDPA of the rounded operands {e_r:.2e}")
+    assert e_r < tol_r
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2), ("f16", 3e-3)])
 def test_attention_key_padding_mask_and_peaked_softmax(prec, tol):
     """attn_mask_enabled path (modules.py:501-506) + a forced running-max jump (one key dominates late)."""
     g = torch.Generator().manual_seed(3)
@@ -87,18 +109,18 @@ def test_attention_key_padding_mask_and_peaked_softmax(prec, tol):
 
 
 def _as_operands(prec, q, k, v):
-    """What the kernel multiplies: the bf16 path rounds k, v and q * attention_q_scale (dim_head^-0.5 * log2 e, attn2.h)
-    to bf16.  With scores of magnitude 100+ that operand rounding moves the softmax far more than any kernel-internal
-    arithmetic, so the extreme-score cases compare against SDPA of the ROUNDED operands."""
-    if prec != "bf16":
+    """What the kernel multiplies: the 16-bit paths round k, v and q * attention_q_scale (dim_head^-0.5 * log2 e, attn2.h)
+    to the operand type.  With scores of magnitude 100+ that operand rounding moves the softmax far more than any
+    kernel-internal arithmetic, so the extreme-score cases compare against SDPA of the ROUNDED operands."""
+    if prec == "f32":
         return q, k, v
     qs = 0.125 * 1.4426950408889634
-    return (q * qs).bfloat16().float() / qs, k.bfloat16().float(), v.bfloat16().float()
+    return rnd(prec, q * qs) / qs, rnd(prec, k), rnd(prec, v)
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2.5e-2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention_reference_tracking_extremes(prec, tol):
-    """The bf16 kernel keeps a lazily updated softmax reference (attn2.h): scores that keep growing tile after tile
+    """The 16-bit kernel keeps a lazily updated softmax reference (attn2.h): scores that keep growing tile after tile
     (reference moves many times), scores that are all very negative (the first-tile reference must follow DOWN or the
     row underflows to 0/0), and rows whose valid keys end inside the first tile / first key half."""
     g = torch.Generator().manual_seed(11)
@@ -122,8 +144,8 @@ def test_attention_reference_tracking_extremes(prec, tol):
     assert (out - sdpa_ref(q, k, v, lens)).abs().max() < tol
 
 
-@pytest.mark.parametrize("D,N,Bp", [(256, 48, 2), (1024, 300, 2), (512, 129, 1), (1024, 1024, 2)])
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("D,N,Bp", [(256, 48, 2), (1024, 300, 2), (512, 129, 1), (1024, 1024, 2), (768, 200, 2)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2), ("f16", 3e-3)])
 def test_convpos_matches_conv1d_mish(D, N, Bp, prec, tol):
     g = torch.Generator().manual_seed(D + N)
     x = torch.randn(Bp, N, D, generator=g).to(DEV)
@@ -133,6 +155,8 @@ def test_convpos_matches_conv1d_mish(D, N, Bp, prec, tol):
     ref = F.mish(F.conv1d(x.permute(0, 2, 1), w, b, padding=15, groups=16)).permute(0, 2, 1) + res
     out = k_convpos(prec, x, w, b, res)
     assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+    ref_r = F.mish(F.conv1d(rnd(prec, x).permute(0, 2, 1), rnd(prec, w), b, padding=15, groups=16)).permute(0, 2, 1) + res
+    assert (out - ref_r).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_convpos_masked_rows():
@@ -162,7 +186,7 @@ def test_layernorm_modulate(D):
     assert (out - ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f32"])
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f32"])
 def test_kernels_are_bitwise_deterministic(prec):
     """Race detector: a stale LDS / register read shows up as run-to-run differences long before it breaks a tolerance
     (an inline-asm VALU consumer of MFMA accumulators did exactly that: nothing pads that hazard)."""

@@ -20,6 +20,7 @@ for st in "$@"; do
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x --timeout 300 ;;
     kernels_all) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 300 ;;
     sample) run sample 900 python -m pytest tests/test_sample_gpu.py -q -m gpu -s --timeout 600 ;;
+    configs) run configs 1100 python -m pytest tests/test_configs_gpu.py -q -m gpu -s --timeout 900 ;;
     gpu_all) run gpu_all 1000 python -m pytest tests -q -m gpu -s --timeout 600 ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 600 python bench.py --steps 5 --warmup 2 ;;
