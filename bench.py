@@ -12,13 +12,24 @@ batch 1, prompt 256 frames, total 1024 frames (768 generated = 8.192 s of 24 kHz
 cfg_strength 2.0, sway -1; synthetic random-init weights (seed 0) and synthetic inputs, all resident in HBM before the
 timed region.  value = generated audio seconds of ALL ranks / wall seconds (the metric as BASELINE.json words it:
 audio_sec / wall_sec, higher is better); rtf_wall_over_audio (the reference's own convention, benchmark.py:457) is
-its inverse.  Scaling is weak: every rank synthesises its own utterance per step.
+its inverse.  `value` scales weakly: every rank synthesises its own utterance per step.
+
+Beside it, every line carries
+  precisions  the same C2 step timed at every operand precision (f32 = exact-f32 MFMA, the parity mode; f16; bf16) with
+              the generated-mel L-inf of that precision against the f32 engine on the same inputs (the f32 engine itself
+              is pinned against the CPU oracle at this size by tests/test_configs_gpu.py): each speed number sits with
+              its own accuracy;
+  c4          BASELINE.json configs[3]: the 256-utterance synthetic set (lengths seed 1234, NFE=16)
+              sharded over the N ranks by dist.dp_sample (cost-balanced partition, length-sorted batches of <= 32, ONE
+              all_gather of the generated mel): wall of the whole job, audio-s per wall-s -- STRONG scaling (total work
+              fixed as N grows; north_star's ">= 6x at 8 GPUs" is c4.value at N=8 over c4.value at N=1).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,7 +39,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -36,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--nfe", type=int, default=16)
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--ref-frames", type=int, default=256)
@@ -44,9 +56,14 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2: B=1 N=1024 NFE=16 (default, the metric's config); c3: B=32 variable-length padded NFE=32; "
                          "c5: E2-TTS UNetT B=8 NFE=16")
+    ap.add_argument("--attn-mask", action="store_true", help="c3: run with attn_mask_enabled=True (padded keys masked)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="Euler steps timed on the host for cpu_baseline")
+    ap.add_argument("--no-precisions", action="store_true", help="skip the per-precision record")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 256-utterance data-parallel job")
+    ap.add_argument("--c4-utts", type=int, default=256)
+    ap.add_argument("--c4-warm-passes", type=int, default=2,
+                    help="untimed passes of the c4 job before the timed one (first: eager, second: HIP-graph capture)")
     ap.add_argument("--setup-runs", type=int, default=3, help="untimed engine-initialisation runs before the warm-up")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: every rank uses cuda:0 and the collectives run on gloo "
@@ -81,10 +98,33 @@ def make_inputs(P, args, rank):
     return cond, text, durs, refs
 
 
+def make_c4_job(P, n_utts):
+    """BASELINE.json configs[3] / SURVEY.md 8(d): n_utts utterances, N_i ~ U{384..1024} (seed 1234; the first is 1024),
+    prompt = N_i // 4 frames of N(0,1) (seed 1), text = round(0.15 N_i) ids.  Identical on every rank."""
+    gl = torch.Generator().manual_seed(1234)
+    durs = [1024] + [int(x) for x in torch.randint(384, 1025, (n_utts - 1,), generator=gl)]
+    g = torch.Generator().manual_seed(1)
+    conds = [torch.randn(d // 4, 100, generator=g) for d in durs]
+    texts = [torch.randint(1, P.config.VOCAB_SIZE - 1, (round(0.15 * d),), generator=g) for d in durs]
+    return conds, texts, durs
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(P, args, sd, vsd, cond, text):
     """The CPU oracle (a port: the reference itself cannot travel to the GPU box) on a bounded sample of the same
-    workload: `cpu_steps` of the NFE Euler steps are timed and scaled (per-step cost does not depend on the step),
-    text encoder and Vocos decode are timed in full."""
+    workload (1 warm-up + 3 timed runs, median): each run times a 1-step and a 2-step sample() of the C2
+    utterance -- their difference is one Euler step (2 DiT forwards with CFG; the per-step cost does not depend on
+    the step), the 1-step run minus one step is the per-utterance fixed part (text encoder, time MLP) -- and the Vocos
+    decode of the generated frames; scaled to NFE steps."""
     from oracle import f5_oracle as O
 
     arch = P.config.F5TTS_BASE
@@ -93,25 +133,32 @@ def cpu_baseline(P, args, sd, vsd, cond, text):
     torch.set_num_threads(cores)
     N = args.frames
     gen = N - args.ref_frames
+    kw = dict(cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, use_epss=False)
+    walls, steps_s, fixed_s, voc_s = [], [], [], []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        out, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=args.cpu_steps, cfg_strength=2.0,
-                          sway_sampling_coef=-1.0, seed=0, use_epss=False)
-        t1 = time.perf_counter()
-        one, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=1, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0,
-                          use_epss=False)
-        t2 = time.perf_counter()
-        O.vocos_decode(vsd, out[:, args.ref_frames:].permute(0, 2, 1))
-        t3 = time.perf_counter()
-    per_step = ((t1 - t0) - (t2 - t1)) / max(args.cpu_steps - 1, 1)
-    fixed = max((t2 - t1) - per_step, 0.0)
-    wall = fixed + per_step * args.nfe + (t3 - t2)
+        out, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=1, **kw)       # warm-up (page-in, thread pool, allocator)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.sample(sd, arch, cond[:1], text[:1], N, steps=1, **kw)
+            t1 = time.perf_counter()
+            out, _ = O.sample(sd, arch, cond[:1], text[:1], N, steps=2, **kw)
+            t2 = time.perf_counter()
+            O.vocos_decode(vsd, out[:, args.ref_frames:].permute(0, 2, 1))
+            t3 = time.perf_counter()
+            per_step = (t2 - t1) - (t1 - t0)
+            fixed = max((t1 - t0) - per_step, 0.0)
+            steps_s.append(per_step)
+            fixed_s.append(fixed)
+            voc_s.append(t3 - t2)
+            walls.append(fixed + per_step * args.nfe + (t3 - t2))
+    wall = statistics.median(walls)
     audio = gen * 256 / 24000
-    return {"value": audio / wall, "unit": "audio_sec/wall_sec", "cores": cores, "kind": "port",
-            "wall_sec_scaled": wall, "rtf_wall_over_audio": wall / audio,
-            "sample": f"CPU oracle (PyTorch fp32, {cores} threads) on the same utterance: {args.cpu_steps} of {args.nfe} "
-                      f"Euler steps timed ({per_step:.2f} s/step) and scaled to NFE={args.nfe}, plus text encoder "
-                      f"({fixed:.2f} s) and Vocos decode of {gen} frames ({t3 - t2:.2f} s) timed in full"}
+    return {"value": audio / wall, "unit": "audio_sec/wall_sec", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "wall_sec_scaled": wall, "wall_sec_scaled_runs": walls, "rtf_wall_over_audio": wall / audio,
+            "sample": f"CPU oracle (PyTorch fp32, {cores} threads) on the C2 utterance, 1 warm-up + 3 timed runs (median): per run a "
+                      f"1-step and a 2-step sample() (difference = one Euler step with CFG: {statistics.median(steps_s):.2f} s, "
+                      f"scaled to NFE={args.nfe}; per-utterance fixed part {statistics.median(fixed_s):.2f} s) and the Vocos "
+                      f"decode of {gen} frames ({statistics.median(voc_s):.2f} s)"}
 
 
 def main():
@@ -146,13 +193,16 @@ def main():
     import f5_tts_amd as P
 
     nv = P.config.VOCAB_SIZE + 1  # load_model: text_num_embeds = vocab_size + 1 (utils_infer.py:313-317)
-    if args.workload == "c5":
-        arch = P.config.E2TTS_BASE
-        tr = P.UNetT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
-    else:
-        arch = P.config.F5TTS_BASE
-        tr = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=args.precision).init_synthetic(seed=0)
-    model = P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(dev)
+
+    def build_model(precision):
+        if args.workload == "c5":
+            tr_ = P.UNetT(**P.config.E2TTS_BASE, text_num_embeds=nv, mel_dim=100, precision=precision).init_synthetic(seed=0)
+        else:
+            arch = dict(P.config.F5TTS_BASE, attn_mask_enabled=bool(args.attn_mask))
+            tr_ = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=precision).init_synthetic(seed=0)
+        return tr_, P.CFM(transformer=tr_, mel_spec_module=P.mel.MelSpec()).to(dev)
+
+    tr, model = build_model(args.precision)
     voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
     cond_cpu, text_cpu, durs, refs = make_inputs(P, args, rank)
     # the prompt mel is resident in HBM; the text ids stay on the host (the reference's API takes list[str]: their
@@ -171,8 +221,8 @@ def main():
     if world > 1:
         gather_buf = torch.empty(world * B, N, 100, device=dev)
 
-    def step():
-        out, _traj = model.sample(cond, text, dur_t, lens=lens_t, **kw)
+    def step(m=None):
+        out, _traj = (m or model).sample(cond, text, dur_t, lens=lens_t, **kw)
         if uniform:
             wav = voc.decode(out[:, ref:, :].permute(0, 2, 1))
         else:  # per item, as the reference's harness does (eval_infer_batch.py:202-206): own prompt / total length
@@ -183,13 +233,20 @@ def main():
                 dist.all_gather_into_tensor(host, out.contiguous().cpu())
                 gather_buf.copy_(host)
             else:
-                dist.all_gather_into_tensor(gather_buf, out.contiguous())
+                dist.all_gather_into_tensor(gather_buf, out)
         return out, wav
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     # engine setup (untimed, before the W warm-up steps): first-use work that is not part of a step -- arena growth,
     # hipFuncSetAttribute on every kernel instantiation, RCCL communicator creation, clock ramp from the idle state
@@ -202,13 +259,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, wav = step()
-    t_enq = time.perf_counter()   # (diagnostic only: when the host finished enqueueing; the metric uses `elapsed`)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cpu" if args.rehearse_one_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(out).all() and torch.isfinite(wav).all()
 
     audio_per_step = gen_frames_total * 256 / 24000
@@ -224,15 +276,43 @@ def main():
         "config": {"workload": {"c2": "C2: F5-TTS Base, 1 utterance/rank/step, prompt %d + generated %d mel frames, NFE=%d EPSS, "
                                       "cfg 2.0, sway -1, Vocos decode, mel all_gather when n_gpus>1" % (ref, gen, args.nfe),
                                 "c3": "C3: F5-TTS Base, %d variable-length utterances/rank/step padded to %d frames (prompt = len/4), "
-                                      "NFE=%d, cfg 2.0, sway -1, per-item Vocos decode" % (B, N, args.nfe),
+                                      "NFE=%d, cfg 2.0, sway -1, attn_mask_enabled=%s, per-item Vocos decode" % (B, N, args.nfe, bool(args.attn_mask)),
                                 "c5": "C5: E2-TTS UNetT Base, %d utterances/rank/step, prompt %d + generated %d frames, NFE=%d, cfg 2.0, "
                                       "sway -1, Vocos decode (BigVGAN is not built)" % (B, ref, gen, args.nfe)}[args.workload],
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }
 
-    # ---- diagnostic split of one step (after the timed region, not part of the metric): where a slow run loses its time
-    phases = {"host_enqueue_ms_per_step": (t_enq - t0) / args.steps * 1e3}
+    # ---- diagnostic split of one step (after the timed region, not part of the metric).  The host side of a step is
+    # measured UNTHROTTLED: the engine's pinned staging ring holds 8 calls, so a host that is more than 8 utterances ahead
+    # of the GPU waits there (back-pressure, an idle wait -- in a long timed region enqueue time per step therefore tends
+    # to the GPU time per step and says nothing about host cost).  Here: 4 steps enqueued from an idle stream.
+    phases = {}
+    torch.cuda.synchronize()
+    rec = {}
+    orig_sample, orig_decode = eng.sample, voc.decode
+
+    def t_sample(*a, **k):
+        a0 = time.perf_counter()
+        r = orig_sample(*a, **k)
+        rec["engine_sample_call"] = rec.get("engine_sample_call", 0.0) + time.perf_counter() - a0
+        return r
+
+    def t_decode(*a, **k):
+        a0 = time.perf_counter()
+        r = orig_decode(*a, **k)
+        rec["vocos_decode_call"] = rec.get("vocos_decode_call", 0.0) + time.perf_counter() - a0
+        return r
+
+    eng.sample, voc.decode = t_sample, t_decode
+    a0 = time.perf_counter()
+    for _ in range(4):
+        step()
+    a1 = time.perf_counter()
+    torch.cuda.synchronize()
+    eng.sample, voc.decode = orig_sample, orig_decode
+    phases["host_enqueue_ms_per_step"] = (a1 - a0) / 4 * 1e3
+    phases["host_ms_per_step_in"] = {k: v / 4 * 1e3 for k, v in rec.items()}   # rest = sample() argument handling + noise draw
     ps, pv = [], []
     for _ in range(3):
         torch.cuda.synchronize()
@@ -259,18 +339,22 @@ def main():
             torch.cuda.synchronize()
             prof = eng.profile_read()
             eng.profile(False)
-            gm, at = prof["gemm"], prof["attention"]
+            gm = prof["gemm"]
             peak = MFMA_PEAK_TFLOPS[args.precision]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            traffic, traffic_source = None, None
+            tfile = os.path.join(ROOT, TRAFFIC_FILE)
             if args.workload == "c2" and args.precision == "bf16" and os.path.exists(tfile):
-                # HBM-side bytes per launch of this kernel class, collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-                # in separate passes over this same command (tools/pmc_bench.sh) and committed under profiles/
-                traffic = json.load(open(tfile))["traffic_bytes_per_launch"]
+                # HBM-side bytes per launch of this kernel class: NOT measured in this run (PMC counters need rocprofv3
+                # around the process); collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this
+                # same command (tools/pmc_bench.sh) and committed under profiles/; refreshed whenever the GEMM changes
+                tj = json.load(open(tfile))
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_source = "%s (%s)" % (TRAFFIC_FILE, tj.get("collected", "rocprofv3 --pmc passes of this command"))
             result["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_tn_glds_kernel (all DiT projections / FFN, fused epilogues)",
                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "traffic_source": traffic_source,
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "flops_per_launch_avg": gm["flops"] / max(gm["launches"], 1),
             }
@@ -281,6 +365,69 @@ def main():
             if args.workload != "c5":  # algorithmic FLOPs on VALID tokens only, so padding waste shows as lost efficiency
                 total_fl = 2 * args.nfe * sum(dit_flops_per_seq_forward(d) for d in durs)
                 result["whole_path_tflops"] = total_fl / (ms_per_step * 1e-3) / 1e12
+
+    # ---- the same step at every operand precision, each with its own accuracy (rank 0 of a 1-GPU run, C2 only)
+    if world == 1 and args.workload == "c2" and not args.no_precisions:
+        ksteps = max(1, min(args.steps, 5))
+        _, ref_model = (tr, model) if args.precision == "f32" else build_model("f32")
+        ref_out, ref_traj = ref_model.sample(cond, text, dur_t, lens=lens_t, **kw)
+        torch.cuda.synchronize()
+        precs = {}
+        for prec in ("f32", "f16", "bf16"):
+            m = model if prec == args.precision else (ref_model if prec == "f32" else build_model(prec)[1])
+            for _ in range(3):   # arena growth, graph capture, clocks
+                step(m)
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for _ in range(ksteps):
+                o_, _w = step(m)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - a) / ksteps * 1e3
+            o2, t2 = m.sample(cond, text, dur_t, lens=lens_t, **kw)
+            precs[prec] = {"ms_per_step": ms, "audio_sec_per_wall_sec": audio_per_step / (ms * 1e-3),
+                           "rtf_wall_over_audio": ms * 1e-3 / audio_per_step,
+                           "mel_linf_vs_f32_engine": float((o2[:, ref:] - ref_out[:, ref:]).abs().max()),
+                           "traj_linf_vs_f32_engine": float((t2 - ref_traj).abs().max()), "steps_timed": ksteps}
+            del m
+        precs["note"] = ("north_star tolerance: 1e-3 mel L-inf against the reference CPU path; the f32 engine is pinned against the "
+                         "CPU oracle at this exact size (N=1024, NFE=16) at <= 1e-5 by tests/test_configs_gpu.py; state magnitude ~8")
+        result["precisions"] = precs
+        del ref_model
+
+    # ---- C4: the 256-utterance job sharded data-parallel over the ranks (strong scaling), one all_gather of the mel
+    if args.workload == "c2" and not args.no_c4:
+        from f5_tts_amd import dist as D
+        conds4, texts4, durs4 = make_c4_job(P, args.c4_utts)
+        conds4 = [c.to(dev) for c in conds4]          # prompts resident in HBM; text ids stay on the host (see above)
+        gen4 = sum(d - d // 4 for d in durs4)
+        kw4 = dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
+
+        def job():
+            return D.dp_sample(model, conds4, texts4, durs4, batch_size=32, device=dev,
+                               collective_on_host=args.rehearse_one_gpu, **kw4)
+
+        for _ in range(args.c4_warm_passes):
+            job()
+        barrier()
+        t0 = time.perf_counter()
+        mels, _lens = job()
+        barrier()
+        el4 = max_over_ranks(time.perf_counter() - t0)
+        assert torch.isfinite(mels).all() and mels.shape == (args.c4_utts, max(durs4), 100)
+        shard_sizes = [len(s) for s in D.partition(durs4, world)]
+        audio4 = gen4 * 256 / 24000
+        result["c4"] = {
+            "workload": "C4: %d synthetic utterances (N_i ~ U{384..1024} seed 1234, prompt N_i/4), F5-TTS Base %s, NFE=16 EPSS, cfg 2.0, "
+                        "sway -1, sharded over %d rank(s) by dist.dp_sample (cost-balanced partition, length-sorted batches of <= 32), "
+                        "ONE all_gather of the generated mel; no vocoder" % (args.c4_utts, args.precision, world),
+            "value": audio4 / el4, "unit": "audio_sec/wall_sec", "scaling": "strong", "n_gpus": world, "wall_sec": el4,
+            "generated_audio_sec": audio4, "utterances_per_rank": shard_sizes,
+            "all_gather_bytes_per_rank": max(shard_sizes) * max(durs4) * 100 * 4,
+            "whole_path_tflops": 2 * 16 * sum(dit_flops_per_seq_forward(d) for d in durs4) / el4 / 1e12,
+        }
+        del mels
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             try:
                 result["cpu_baseline"] = cpu_baseline(P, args, tr.state_dict(), voc.state_dict(), cond_cpu, text_cpu)

@@ -96,13 +96,14 @@ int f5_dit_forward(f5_engine* e, const float* x, const float* cond, const int64_
 /* The ODE solve of CFM.sample (cfm.py:151-223): step_cond = where(cond_mask, cond, 0); `steps` Euler steps over the
  * HOST time grid t[steps + 1] with classifier-free guidance (cfg_strength < 1e-5 -> single conditional forward);
  * out = where(cond_mask, cond, y_final).
- *   cond f32[B, N, mel] (already padded to N; zeros for no_ref_audio), cond_mask u8[B, N], y0 f32[B, N, mel],
+ *   cond f32[B, cond_frames, mel] (cond_frames <= N; the frames cond_frames .. N-1 read as zero: the reference's
+ *   F.pad(cond, (0, 0, 0, N - cond_seq_len)), cfm.py:145; cond_frames = 0 is no_ref_audio), cond_mask u8[B, N], y0 f32[B, N, mel],
  *   text i64[B, nt], lens HOST int32[B] = per-sample durations or NULL when B == 1 (cfm.py:155-158),
  *   out f32[B, N, mel], traj f32[steps + 1, B, N, mel] or NULL.
  * The text embeddings are computed once per call (the reference's per-sample() cache, dit.py:244-269). */
-int f5_sample(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
-              int32_t nt, const float* t_host, int32_t steps, float cfg_strength, const int32_t* lens_host, int32_t B,
-              int32_t N, float* out, float* traj, f5_stream stream);
+int f5_sample(f5_engine* e, const float* cond, int32_t cond_frames, const uint8_t* cond_mask, const float* y0,
+              const int64_t* text, int32_t nt, const float* t_host, int32_t steps, float cfg_strength,
+              const int32_t* lens_host, int32_t B, int32_t N, float* out, float* traj, f5_stream stream);
 
 /* Pre-sizes the activation arena (otherwise it grows on first use, which calls hipMalloc inside f5_sample). */
 int f5_reserve(f5_engine* e, int32_t max_batch, int32_t max_frames, int32_t max_steps);
@@ -127,6 +128,11 @@ int f5_vocos_load_weight(f5_vocos* v, const char* name, const void* dev_f32, con
 int f5_vocos_finalize(f5_vocos* v, f5_stream stream);
 /* mel f32[B, C, T] -> wav f32[B, (T - 1) * hop]   (Vocos.decode: backbone -> ISTFTHead, padding="center") */
 int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t T, float* wav, f5_stream stream);
+/* The same with mel addressed as mel[b * stride_b + c * stride_c + t * stride_t] (element strides): the callers'
+ * `vocoder.decode(generated.permute(0, 2, 1))` (utils_infer.py:702-703) passes a transposed VIEW of sample()'s [B, T, C]
+ * output, which is decoded in place instead of through a transposing copy. */
+int f5_vocos_decode_strided(f5_vocos* v, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_c,
+                            int64_t stride_t, float* wav, f5_stream stream);
 
 /* ------------------------------------------------------------------------------------- prompt mel front-end
  * MelSpec.forward, mel_spec_type="vocos" (model/modules.py:78-146): wav f32[B, nw] -> log-mel f32[B, T, n_mels],

@@ -21,7 +21,7 @@ def __getattr__(name):  # lazy: importing the package must not require the built
     if name == "lib":
         from . import _lib
         return _lib
-    if name in ("infer", "dist", "batching"):
+    if name in ("infer", "dist", "batching", "engine"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

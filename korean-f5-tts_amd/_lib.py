@@ -45,13 +45,14 @@ SIGNATURES = {
     "f5_finalize": (_i, [_p, _p]),
     "f5_text_embed": (_i, [_p, _p, _i, _i, C.POINTER(_i), _i, _i, _p, _p]),
     "f5_dit_forward": (_i, [_p, _p, _p, _p, _i, C.POINTER(_f), C.POINTER(_i), _i, _i, _i, _i, _i, _p, _p]),
-    "f5_sample": (_i, [_p, _p, _p, _p, _p, _i, C.POINTER(_f), _i, _f, C.POINTER(_i), _i, _i, _p, _p, _p]),
+    "f5_sample": (_i, [_p, _p, _i, _p, _p, _p, _i, C.POINTER(_f), _i, _f, C.POINTER(_i), _i, _i, _p, _p, _p]),
     "f5_reserve": (_i, [_p, _i, _i, _i]),
     "f5_vocos_create": (_i, [C.POINTER(f5_vocos_config), C.POINTER(_p)]),
     "f5_vocos_destroy": (_i, [_p]),
     "f5_vocos_load_weight": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),
     "f5_vocos_finalize": (_i, [_p, _p]),
     "f5_vocos_decode": (_i, [_p, _p, _i, _i, _p, _p]),
+    "f5_vocos_decode_strided": (_i, [_p, _p, _i, _i, C.c_int64, C.c_int64, C.c_int64, _p, _p]),
     "f5_mel_create": (_i, [_i, _i, _i, C.POINTER(_p)]),
     "f5_mel_destroy": (_i, [_p]),
     "f5_mel_load": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),

@@ -85,10 +85,9 @@ class CFM(nn.Module):
 
         if duplicate_test:
             test_cond = F.pad(cond, (0, 0, cond_seq_len, N - 2 * cond_seq_len), value=0.0)
-        cond = F.pad(cond, (0, 0, 0, N - cond_seq_len), value=0.0)
-        if no_ref_audio:
-            cond = torch.zeros_like(cond)
-        cond_mask = F.pad(cond_mask, (0, N - cond_mask.shape[-1]), value=False)
+        # cond = F.pad(cond, (0, 0, 0, N - cond_seq_len)) (cfm.py:145) happens inside the engine: the prompt goes down
+        # unpadded with its frame count; no_ref_audio (cfm.py:146-147: an all-zero cond) is "zero prompt frames"
+        cond_mask = F.pad(cond_mask, (0, N - cond_mask.shape[-1]), value=False)   # (host tensor)
 
         # noise (cfm.py:196-201): same seed for every sample, drawn per sample at its own length, zero padded
         y0 = []
@@ -112,7 +111,7 @@ class CFM(nn.Module):
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
 
         eng = self.transformer.engine()
-        out, trajectory = eng.sample(cond, cond_mask, y0, text_cpu, t.tolist(), cfg_strength,
+        out, trajectory = eng.sample(None if no_ref_audio else cond, cond_mask, y0, text_cpu, t.tolist(), cfg_strength,
                                      lens=duration.tolist() if batch > 1 else None, want_traj=True)
         self.transformer.clear_cache()
         if exists(vocoder):

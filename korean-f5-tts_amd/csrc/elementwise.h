@@ -427,8 +427,11 @@ __global__ void cast_pad_kernel(const float* __restrict__ in, int ld_in, int row
 }
 
 // ------------------------------------------------------------------------------------------------ Vocos
-// A[b*T + t][k*C + ci] = mel[b][ci][t + k - 3]  (Conv1d(C, dim, k=7, pad=3) as a GEMM); columns >= 7*C zero (K padding)
-static __global__ void im2col7_kernel(const float* __restrict__ mel, float* __restrict__ A, int B, int C, int T, int ld) {
+// A[b*T + t][k*C + ci] = mel[b][ci][t + k - 3]  (Conv1d(C, dim, k=7, pad=3) as a GEMM); columns >= 7*C zero (K padding).
+// mel is read through element strides (sb, sc, st), so the [B, T, C] mel that sample() returns can be decoded through
+// the reference's `vocoder.decode(mel.permute(0, 2, 1))` view without a transposing copy.
+static __global__ void im2col7_kernel(const float* __restrict__ mel, long sb, long sc, long st, float* __restrict__ A, int B, int C,
+                                      int T, int ld) {
     const long total = (long)B * T * ld;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int col = (int)(i % ld);
@@ -438,7 +441,7 @@ static __global__ void im2col7_kernel(const float* __restrict__ mel, float* __re
         if (col < 7 * C) {
             const int k = col / C, ci = col - k * C;
             const int tt = t + k - 3;
-            if (tt >= 0 && tt < T) v = mel[((size_t)b * C + ci) * T + tt];
+            if (tt >= 0 && tt < T) v = mel[b * sb + ci * sc + tt * st];
         }
         A[i] = v;
     }

@@ -172,11 +172,12 @@ bool graphs_enabled(f5_engine* e) {
     }
     return e->graphs_on == 1;
 }
-extern "C" int f5_sample(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
-                         int32_t nt, const float* t_host, int32_t steps, float cfg_strength, const int32_t* lens_host,
-                         int32_t B, int32_t N, float* out, float* traj, f5_stream stream) {
+extern "C" int f5_sample(f5_engine* e, const float* cond, int32_t cond_frames, const uint8_t* cond_mask, const float* y0,
+                         const int64_t* text, int32_t nt, const float* t_host, int32_t steps, float cfg_strength,
+                         const int32_t* lens_host, int32_t B, int32_t N, float* out, float* traj, f5_stream stream) {
     CHK(check_ready(e, B, N));
-    if (!cond || !cond_mask || !y0 || !text || !t_host || !out || nt <= 0 || steps <= 0)
+    if ((!cond && cond_frames > 0) || !cond_mask || !y0 || !text || !t_host || !out || nt <= 0 || steps <= 0 || cond_frames < 0 ||
+        cond_frames > N)
         return fail(F5_EINVAL, "f5_sample: bad arguments");
     if (B > 1 && !lens_host) return fail(F5_EINVAL, "f5_sample: lens required when B > 1 (cfm.py:155-158)");
     if (lens_host)
@@ -184,7 +185,7 @@ extern "C" int f5_sample(f5_engine* e, const float* cond, const uint8_t* cond_ma
             if (lens_host[i] <= 0 || lens_host[i] > N) return fail(F5_EINVAL, "lens[%d]=%d out of (0, N]", i, lens_host[i]);
     hipStream_t s = (hipStream_t)stream;
     e->prof.clear();
-    return F5_OPS(e, sample(e, cond, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s));
+    return F5_OPS(e, sample(e, cond, cond_frames, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s));
 }
 
 extern "C" int f5_profile_enable(f5_engine* e, int32_t on) {

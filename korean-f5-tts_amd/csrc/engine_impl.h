@@ -667,7 +667,7 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
     return F5_OK;
 }
 template <typename T>
-static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text,
+static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const uint8_t* cond_mask, const float* y0, const int64_t* text,
                        int nt, const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N,
                        float* out, float* traj, hipStream_t s) {
     const int mel = e->cfg.mel_dim;
@@ -681,7 +681,10 @@ static int sample_impl(f5_engine* e, const float* cond, const uint8_t* cond_mask
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     // ---- inputs -> arena (eager, on the caller's stream)
     CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, chunk_utts(e, B, N, !(cfg_strength < 1e-5f))));
-    HIPCHK(hipMemcpyAsync(w.in_cond, cond, half * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (cond_frames < N) HIPCHK(hipMemsetAsync(w.in_cond, 0, half * sizeof(float), s));   // F.pad(cond, ..., N - cond_seq_len) (cfm.py:145)
+    if (cond_frames > 0)
+        HIPCHK(hipMemcpy2DAsync(w.in_cond, (size_t)N * mel * sizeof(float), cond, (size_t)cond_frames * mel * sizeof(float),
+                                (size_t)cond_frames * mel * sizeof(float), B, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(w.y, y0, half * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(w.in_mask, cond_mask, (size_t)B * N, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(w.in_text, text, (size_t)B * nt * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -765,8 +768,8 @@ int EngineOps<T>::forward(f5_engine* e, const float* x, const float* cond, const
     return forward_impl<T>(e, x, cond, text, nt, time_host, lens_host, B, N, cfg_infer, drop_audio_cond, drop_text, out, s);
 }
 template <typename T>
-int EngineOps<T>::sample(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text, int nt,
+int EngineOps<T>::sample(f5_engine* e, const float* cond, int cond_frames, const uint8_t* cond_mask, const float* y0, const int64_t* text, int nt,
                          const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N, float* out,
                          float* traj, hipStream_t s) {
-    return sample_impl<T>(e, cond, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s);
+    return sample_impl<T>(e, cond, cond_frames, cond_mask, y0, text, nt, t_host, steps, cfg_strength, lens_host, B, N, out, traj, s);
 }

@@ -262,7 +262,7 @@ template <typename T> struct EngineOps {
     static int forward(f5_engine* e, const float* x, const float* cond, const int64_t* text, int nt, const float* time_host,
                        const int32_t* lens_host, int B, int N, int cfg_infer, int drop_audio_cond, int drop_text, float* out,
                        hipStream_t s);
-    static int sample(f5_engine* e, const float* cond, const uint8_t* cond_mask, const float* y0, const int64_t* text, int nt,
+    static int sample(f5_engine* e, const float* cond, int cond_frames, const uint8_t* cond_mask, const float* y0, const int64_t* text, int nt,
                       const float* t_host, int steps, float cfg_strength, const int32_t* lens_host, int B, int N, float* out,
                       float* traj, hipStream_t s);
 };

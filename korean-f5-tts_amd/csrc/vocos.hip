@@ -177,6 +177,12 @@ extern "C" int f5_vocos_finalize(f5_vocos* v, f5_stream stream) {
 }
 
 extern "C" int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t T, float* wav, f5_stream stream) {
+    if (!v) return fail(F5_EINVAL, "f5_vocos_decode: null argument");
+    return f5_vocos_decode_strided(v, mel, B, T, (int64_t)v->cfg.input_channels * T, T, 1, wav, stream);
+}
+
+extern "C" int f5_vocos_decode_strided(f5_vocos* v, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_c,
+                                       int64_t stride_t, float* wav, f5_stream stream) {
     if (!v || !mel || !wav) return fail(F5_EINVAL, "f5_vocos_decode: null argument");
     if (!v->finalized) return fail(F5_ESTATE, "f5_vocos_finalize has not been called");
     if (B <= 0 || T < 2) return fail(F5_EINVAL, "f5_vocos_decode: need B >= 1 and T >= 2 frames");
@@ -209,7 +215,8 @@ extern "C" int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t
     }
     (void)plan(v->arena, &col, &x, &t1, &h, &hd, &S, &fr);
 
-    hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks(R * v->kemb)), dim3(256), 0, s, mel, col, B, C, T, v->kemb);
+    hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks(R * v->kemb)), dim3(256), 0, s, mel, (long)stride_b, (long)stride_c,
+                       (long)stride_t, col, B, C, T, v->kemb);
     KCHK();
     HIPCHK(launch_gemm<float>(s, col, v->kemb, v->emb_w, v->kemb, (int)R, D, v->kemb, EpiStore<float>{t1, D, v->emb_b, F5_ACT_NONE}));
     hipLaunchKernelGGL((layernorm_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, s, t1, D, x, D, (int)R, D, 1e-6f, v->n0w,

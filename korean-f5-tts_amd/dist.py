@@ -38,12 +38,13 @@ def batches_of(shard: list[int], durations: list[int], batch_size: int) -> list[
 
 @torch.no_grad()
 def dp_sample(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durations: list[int], *, batch_size: int = 32,
-              group=None, device=None, **sample_kw):
+              group=None, device=None, collective_on_host: bool = False, **sample_kw):
     """Synthesises every utterance of the job on its owner rank and returns ALL mels on every rank.
 
     conds[i]: f32[ref_i, mel] prompt mel; texts[i]: i64[nt_i]; durations[i]: total frames.
     Returns (mels, lens): mels f32[n_utt, N_max, mel] in the original order (zero padded), lens list[int].
     Exactly one collective: all_gather_into_tensor of a [per_rank_max, N_max, mel] buffer.
+    collective_on_host: run that collective on host copies (rehearsals of N ranks on ONE GPU over gloo only).
     """
     import os
 
@@ -65,16 +66,25 @@ def dp_sample(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durat
         text = torch.nn.utils.rnn.pad_sequence([texts[u] for u in batch], batch_first=True, padding_value=-1)
         dur = torch.tensor([durations[u] for u in batch], dtype=torch.long)
         out, _ = model.sample(cond, text, dur, lens=torch.tensor(ref_lens, dtype=torch.long), **sample_kw)
-        for j, u in enumerate(batch):
-            local[slot[u], :durations[u]] = out[j, :durations[u]].to(local.dtype)
+        # the batch's rows go to their slots in ONE masked scatter (frames past an utterance's own length are zeroed)
+        nb = out.shape[1]
+        valid = (torch.arange(nb)[None, :] < dur[:, None]).to(device=device, dtype=local.dtype, non_blocking=True)
+        idx = torch.tensor([slot[u] for u in batch], dtype=torch.long).to(device, non_blocking=True)
+        local[:, :nb].index_copy_(0, idx, out.to(local.dtype) * valid[..., None])
     if world == 1:
         gathered = local.unsqueeze(0)
     else:
-        flat = torch.empty(world * per_rank, n_max, mel_dim, device=device, dtype=torch.float32)
-        dist.all_gather_into_tensor(flat, local, group=group)   # the ONE exchange of the job
+        if collective_on_host:
+            host = torch.empty(world * per_rank, n_max, mel_dim, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, local.cpu(), group=group)
+            flat = host.to(device)
+        else:
+            flat = torch.empty(world * per_rank, n_max, mel_dim, device=device, dtype=torch.float32)
+            dist.all_gather_into_tensor(flat, local, group=group)   # the ONE exchange of the job
         gathered = flat.view(world, per_rank, n_max, mel_dim)
-    mels = torch.zeros(len(durations), n_max, mel_dim, device=device, dtype=torch.float32)
+    where = [0] * len(durations)                      # original order: one gather over the [world * per_rank] slots
     for r, shard in enumerate(shards):
         for k, u in enumerate(shard):
-            mels[u] = gathered[r, k]
+            where[u] = r * per_rank + k
+    mels = gathered.reshape(world * per_rank, n_max, mel_dim).index_select(0, torch.tensor(where, dtype=torch.long).to(device))
     return mels, list(durations)

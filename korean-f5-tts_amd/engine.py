@@ -141,17 +141,20 @@ class Engine:
         return out
 
     def sample(self, cond, cond_mask, y0, text, t_grid, cfg_strength, lens=None, want_traj=True):
-        """cond f32[B,N,mel] (padded), cond_mask bool[B,N], y0 f32[B,N,mel], text i64[B,nt], t_grid list[float]."""
-        B, N, mel = cond.shape
+        """cond f32[B,Nc,mel] (Nc <= N: the engine zero-pads, cfm.py:145; None = no_ref_audio), cond_mask bool[B,N],
+        y0 f32[B,N,mel], text i64[B,nt], t_grid list[float]."""
+        B, N, mel = y0.shape
+        cond_frames = 0 if cond is None else cond.shape[1]
         steps = len(t_grid) - 1
-        cond = _h2d_async(cond, self.device, torch.float32)
+        if cond is not None:
+            cond = _h2d_async(cond, self.device, torch.float32)
         y0 = _h2d_async(y0, self.device, torch.float32)
         cm = _h2d_async(cond_mask, self.device, torch.uint8)
         text = _h2d_async(text, self.device, torch.long)
         out = torch.empty(B, N, mel, device=self.device, dtype=torch.float32)
         traj = torch.empty(steps + 1, B, N, mel, device=self.device, dtype=torch.float32) if want_traj else None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.f5_sample(self._h, _ptr(cond), _ptr(cm), _ptr(y0), _ptr(text), text.shape[1],
+            _lib.check(self.lib.f5_sample(self._h, _ptr(cond), cond_frames, _ptr(cm), _ptr(y0), _ptr(text), text.shape[1],
                                           _lib.float_array(t_grid), steps, float(cfg_strength), _lib.int_array(lens),
                                           B, N, _ptr(out), _ptr(traj), _stream_ptr(self.device)), "f5_sample")
         return out, traj

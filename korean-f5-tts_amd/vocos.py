@@ -112,12 +112,15 @@ class Vocos(nn.Module):
         """mel f32[B, C, T] -> wav f32[B, (T - 1) * hop]."""
         h = self._handle()
         dev = self._anchor.device
-        mel = _dev_f32(mel, dev)
+        if mel.device != dev or mel.dtype != torch.float32:
+            mel = mel.detach().to(device=dev, dtype=torch.float32)
         B, Cc, T = mel.shape
         assert Cc == self.cfg["input_channels"]
         wav = torch.empty(B, (T - 1) * self.cfg["hop_length"], device=dev, dtype=torch.float32)
+        sb, sc, st = mel.stride()   # any view: the callers pass sample()'s [B, T, C] output as .permute(0, 2, 1)
         with torch.cuda.device(dev):
-            _lib.check(_lib.load().f5_vocos_decode(h, _ptr(mel), B, T, _ptr(wav), _stream_ptr(dev)), "f5_vocos_decode")
+            _lib.check(_lib.load().f5_vocos_decode_strided(h, _ptr(mel), B, T, sb, sc, st, _ptr(wav), _stream_ptr(dev)),
+                       "f5_vocos_decode")
         return wav
 
     def forward(self, mel):
