@@ -16,7 +16,9 @@
 //
 // Block = 4 waves x 32 q rows = 128 q rows of one (b', h); KV tiles of 64 keys, double-buffered in LDS with register
 // prefetch (one barrier per tile).  Keys >= kv_len (the sample's own length when the reference's attn_mask_enabled is
-// set, else N) are masked; K/V tiles beyond kv_len are never loaded.
+// set, else N) are masked; K/V tiles beyond kv_len are never loaded.  Query blocks that lie wholly past q_lens[b] (the
+// sample's own length in a padded batch) exit at once: the reference zeroes those rows of the attention output
+// (modules.py:540-542, here the row mask of the out-projection epilogue), so nothing reads them.
 #pragma once
 #include "gemm.h"
 
@@ -25,8 +27,10 @@ namespace f5 {
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                        const T* __restrict__ Vt, T* __restrict__ O, int H, int N,
-                                                       int Npad, const int* __restrict__ kv_lens, int nbatch_lens) {
+                                                       int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
+                                                       const int* __restrict__ q_lens) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (q_lens && (int)blockIdx.x * 128 >= q_lens[blockIdx.z % nbatch_lens]) return;   // (block-uniform, before any barrier)
     constexpr int RB = 64 * sizeof(T);          // bytes per 64-element row (128 / 256)
     constexpr int RS = RB + 16;                 // padded LDS row stride
     constexpr int NF = RB / 64;                 // 16-byte fragments per lane per 64-element row (2 / 4)
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
 
 template <typename T>
 inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H, int N,
-                                   int Npad, const int* kv_lens, int nbatch_lens) {
+                                   int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr) {
     constexpr int smem = 2 * 2 * 64 * (64 * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -210,7 +214,7 @@ inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const 
         attr_set = true;
     }
     dim3 grid((N + 127) / 128, H, Bp);
-    hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens);
+    hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens);
     return hipGetLastError();
 }
 

@@ -121,23 +121,31 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
 
+    // epilogue operands first (clamped rows, no bounds branches around the loads), ONE visible wait, then the guarded
+    // stores: a store that is the first use of a pending load inside an exec-masked block makes hipcc wait vmcnt(0) -- for
+    // the previous store's round trip -- in front of every store (gemm2.h)
+    float4 bi[NJ], rv[2][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4*>(bias + grp * CPG + j * 16 + g * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tokc = min(tok0 + wave * 32 + i * 16 + l15, N - 1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            rv[i][j] = res ? *reinterpret_cast<const float4*>(res + ((size_t)b * N + tokc) * D + grp * CPG + j * 16 + g * 4)
+                           : make_float4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int tok = tok0 + wave * 32 + i * 16 + l15;
-        if (tok >= N) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int co = grp * CPG + j * 16 + g * 4;
-            const float4 bi = *reinterpret_cast<const float4*>(bias + co);
-            float4 v = make_float4(acc[i][j][0] + bi.x, acc[i][j][1] + bi.y, acc[i][j][2] + bi.z, acc[i][j][3] + bi.w);
+            float4 v = make_float4(acc[i][j][0] + bi[j].x, acc[i][j][1] + bi[j].y, acc[i][j][2] + bi[j].z, acc[i][j][3] + bi[j].w);
             if (tok >= len) v = make_float4(0, 0, 0, 0);
-            v.x = mish(v.x); v.y = mish(v.y); v.z = mish(v.z); v.w = mish(v.w);
-            const size_t off = ((size_t)b * N + tok) * D + co;
-            if (res) {
-                const float4 r = *reinterpret_cast<const float4*>(res + off);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-            }
-            *reinterpret_cast<float4*>(Y + off) = v;
+            v.x = mish(v.x) + rv[i][j].x; v.y = mish(v.y) + rv[i][j].y; v.z = mish(v.z) + rv[i][j].z; v.w = mish(v.w) + rv[i][j].w;
+            if (tok < N) *reinterpret_cast<float4*>(Y + ((size_t)b * N + tok) * D + co) = v;
         }
     }
 }

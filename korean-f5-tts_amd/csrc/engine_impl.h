@@ -357,7 +357,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
@@ -454,7 +454,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
         HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
@@ -701,11 +701,19 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
     const std::string base_key(kb);
     const std::string key = base_key + (uc_hit ? "|uc" : "|nouc");
     bool done = false;
+    static const bool trace = getenv("F5_TRACE") && getenv("F5_TRACE")[0] == '1';   // diagnostic: which path a call takes
+    const auto t_body = std::chrono::steady_clock::now();
+    auto trace_done = [&](const char* how) {
+        if (trace)
+            fprintf(stderr, "libf5hip: sample %s [%s]: host %.3f ms\n", key.c_str(), how,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_body).count());
+    };
     if (graphs_enabled(e) && !e->prof.on && !uc_store) {
         for (auto& g : e->graphs)
             if (g.key == key) {
                 HIPCHK(hipGraphLaunch(g.exec, s));
                 done = true;
+                trace_done("graph replay");
                 break;
             }
         const bool is_warm = std::find(e->warm.begin(), e->warm.end(), base_key) != e->warm.end();
@@ -725,6 +733,7 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
                     e->graphs.push_back({key, graph, exec});
                     HIPCHK(hipGraphLaunch(exec, s));
                     done = true;
+                    trace_done("graph capture + instantiate + launch");
                 } else {
                     // capture is an optimisation: fall back to eager launches, but say so (the wall time doubles on a busy host)
                     fprintf(stderr, "libf5hip: HIP graph capture of sample() failed (body rc %d, end-capture: %s, last: %s); "
@@ -741,6 +750,7 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
     }
     if (!done) {
         CHK(sample_body<T>(e, w, nt, steps, cfg_strength, lens_host != nullptr, B, N, traj != nullptr, s));
+        trace_done("eager launches");
         if (std::find(e->warm.begin(), e->warm.end(), base_key) == e->warm.end()) e->warm.push_back(base_key);
     }
     // ---- outputs -> caller

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>

@@ -296,6 +296,11 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         return;
     }
     if (!EARLY) epilogue_setup();
+    // Every memory operand of the epilogue (bias, residual, gate, rotary table) has been requested by now; retire them with
+    // ONE wait the compiler can see.  Without it hipcc's wait-count pass -- which cannot see the loop's asm waits and has to
+    // merge the "pending load" state across the exec-masked bounds checks around each store -- puts `s_waitcnt vmcnt(0)` in
+    // front of EVERY store: each store then waits for the previous one's round trip (4-12 serialized stores per lane).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = nw + j * 16 + g * 4;

@@ -1,28 +1,32 @@
 // launch_gemm(): picks the kernel and tile for C[M,N] = A[M,K] W[N,K]^T + epilogue.
 //   v2 (gemm2.h, LDS-DMA ring) whenever K is a whole number of 128-byte K-tiles (the engine pads its operands so
-//   that this always holds on the hot path); v1 (gemm.h, register-staged, any K % 16 bytes == 0) otherwise.
+//   that this always holds on the hot path); v3 (gemm3.h, 256x256 ping-pong) for many-row problems that fill the chip
+//   with such tiles (the utterance batches of C3 / C4); v1 (gemm.h, register-staged, any K % 16 bytes == 0) otherwise.
 // Tile choice (measured on MI355X at M = 2048, tools/gemm2_sweep.py): the B=1 shapes are latency / L2-bandwidth
 // bound, so the tile is the largest one that still yields >= ~1 workgroup per CU.
 #pragma once
-#include "gemm2.h"
+#include "gemm3.h"
 
 namespace f5 {
 
-enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10, G2_256x128_8W = 13 };
+enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10, G2_256x128_8W = 13, G3_256x256_PP = 20 };
 
 // cost = rounds of workgroups over the 256 CUs x the time of one tile of that shape (us at K = 1024, measured with
 // tools/gemm2_sweep.py on a full chip: the per-K-step time grows much more slowly than the tile area, so the largest
 // tile that does not add a round wins; e.g. the QKV projection 2048 x 3072: 128x128 = 384 tiles = 2 rounds (25 us),
 // 128x192 = 256 tiles = 1 round (20 us)).
-inline int pick_cfg_v2(int M, int N) {
+inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
     if (M <= 64) return G2_64x64_4W;  // skinny (time MLP, AdaLN stack over the NFE steps): weight-streaming, no row reuse to gain
     struct Cand { int id, bm, bn; float t; };
     // (256x128: 865 TFLOP/s at M = 16384, N = 2048 against 722 for 128x128: the many-utterance batches C3 / C4)
-    static const Cand cands[] = {{G2_256x128_8W, 256, 128, 21.0f}, {G2_128x192_8W, 128, 192, 19.3f}, {G2_128x128_8W, 128, 128, 14.5f},
-                                 {G2_128x64_8W, 128, 64, 7.3f}, {G2_64x64_4W, 64, 64, 4.0f}};
+    // (256x256 ping-pong, gemm3.h: 16384 x {1024, 2048, 3072} x 1024 in 39 / 74 / 110 us = 37 us per round of 256 tiles against
+    //  42 us for two rounds of 256x128 tiles; 1.22 PFLOP/s in the K loop against 1.02)
+    static const Cand cands[] = {{G3_256x256_PP, 256, 256, 37.0f}, {G2_256x128_8W, 256, 128, 21.0f}, {G2_128x192_8W, 128, 192, 19.3f},
+                                 {G2_128x128_8W, 128, 128, 14.5f}, {G2_128x64_8W, 128, 64, 7.3f}, {G2_64x64_4W, 64, 64, 4.0f}};
     int best = G2_64x64_4W;
     float best_cost = 3.0e38f;
     for (const Cand& c : cands) {
+        if (c.id == G3_256x256_PP && !allow_v3) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         const float cost = (float)((tiles + 255) / 256) * c.t;
         if (cost < best_cost) { best_cost = cost; best = c.id; }  // ties keep the larger tile (listed first)
@@ -34,6 +38,7 @@ template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                  const Epi& epi, int cfg) {
     switch (cfg) {
+        case G3_256x256_PP: return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
@@ -47,7 +52,8 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
                               const Epi& epi, int force_cfg = -1) {
     if (M <= 0 || N <= 0) return hipSuccess;
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
-    if (K % KT == 0 && force_cfg != -2) return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, force_cfg >= 0 ? force_cfg : pick_cfg_v2(M, N));
+    if (K % KT == 0 && force_cfg != -2)
+        return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, force_cfg >= 0 ? force_cfg : pick_cfg_v2(M, N, sizeof(T) == 2 && gemm3_epilogue_ok(epi)));
     return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }
 

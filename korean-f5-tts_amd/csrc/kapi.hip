@@ -35,7 +35,7 @@ extern "C" int f5k_gemm(int32_t prec, const float* A, const float* W, const floa
                         int32_t N, int32_t K, int32_t tm, int32_t tn, f5_stream stream) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || (N % 4)) return fail(F5_EINVAL, "f5k_gemm: bad arguments (N %% 4 == 0)");
     if (tm > 0 && !((tm == 128 && (tn == 128 || tn == 64)) || (tm == 64 && tn == 64))) return fail(F5_EINVAL, "f5k_gemm: bad tile");
-    if (tm < 0 && tm != -2 && tm != -8 && tm != -9) return fail(F5_EINVAL, "f5k_gemm: bad v2 config id");
+    if (tm < 0 && tm != -2 && tm != -8 && tm != -9 && tm != -10 && tm != -13 && tm != -20) return fail(F5_EINVAL, "f5k_gemm: bad v2 / v3 config id");
     hipStream_t s = (hipStream_t)stream;
     return F5K_BY_PREC(prec, gemm_impl, A, W, bias, act, out, M, N, K, tm, tn, s);
 }
@@ -189,6 +189,7 @@ static hipError_t gemm2_dispatch(int cfg, hipStream_t s, const T* A, int lda, co
         case 0: return launch_gemm2_cfg<T, 128, 128, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 1: return launch_gemm2_cfg<T, 128, 128, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 13: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi);
+        case 20: return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 2: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 3: return launch_gemm2_cfg<T, 128, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
         case 5: return launch_gemm2_cfg<T, 64, 64, 2, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi);
