@@ -28,7 +28,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                        const T* __restrict__ Vt, T* __restrict__ O, int H, int N,
                                                        int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
-                                                       const int* __restrict__ q_lens) {
+                                                       const int* __restrict__ q_lens, const int* __restrict__ o_row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (q_lens && (int)blockIdx.x * 128 >= q_lens[blockIdx.z % nbatch_lens]) return;   // (block-uniform, before any barrier)
     constexpr int RB = 64 * sizeof(T);          // bytes per 64-element row (128 / 256)
@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
         const int q = q0 + qs * 16 + l15;
-        if (q < N) {
-            T* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
+        // (o_row_start: output rows of a packed variable-length batch, RowPack: batch row b owns rows o_row_start[b] ..)
+        const size_t orow = o_row_start ? (size_t)o_row_start[b] + q : (size_t)b * N + q;
+        if (q < (o_row_start ? min(N, o_row_start[b + 1] - o_row_start[b]) : N)) {
+            T* dst = O + orow * (H * 64) + h * 64 + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 store4(dst + dt * 16, o[dt][qs][0] * inv, o[dt][qs][1] * inv, o[dt][qs][2] * inv, o[dt][qs][3] * inv);
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
 
 template <typename T>
 inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H, int N,
-                                   int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr) {
+                                   int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
+                                   const int* o_row_start = nullptr) {
     constexpr int smem = 2 * 2 * 64 * (64 * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -214,7 +217,7 @@ inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const 
         attr_set = true;
     }
     dim3 grid((N + 127) / 128, H, Bp);
-    hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens);
+    hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
     return hipGetLastError();
 }
 

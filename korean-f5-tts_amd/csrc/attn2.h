@@ -227,7 +227,8 @@ template <typename T, int VAR>
 __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                                const T* __restrict__ Vt, T* __restrict__ O, int H,
                                                                int N, int Npad, const int* __restrict__ kv_lens,
-                                                               int nbatch_lens, const int* __restrict__ q_lens) {
+                                                               int nbatch_lens, const int* __restrict__ q_lens,
+                                                               const int* __restrict__ o_row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // query blocks wholly past the sample's own length (padded batches): their output rows are zeroed by the reference
     // (modules.py:540-542; here: never read, the out-projection epilogue masks those rows) -- exit before any barrier
@@ -353,8 +354,10 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q,
             const float a0 = exp2f(mrun[qs] - m), a1 = exp2f(m1 - m);   // maxima are kept in log2 units
             const float inv = 1.0f / (lrun[qs] * a0 + l1 * a1);
             const int q = q0 + qs * 16 + l15;
-            if (q < N) {
-                T* dst = O + ((size_t)b * N + q) * (H * 64) + h * 64 + g * 4;
+            // (o_row_start: output rows of a packed variable-length batch, RowPack: batch row b owns rows o_row_start[b] ..)
+            const size_t orow = o_row_start ? (size_t)o_row_start[b] + q : (size_t)b * N + q;
+            if (q < (o_row_start ? min(N, o_row_start[b + 1] - o_row_start[b]) : N)) {
+                T* dst = O + orow * (H * 64) + h * 64 + g * 4;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     float v[4];
@@ -377,7 +380,7 @@ template <> inline float attention_q_scale<bf16_t>() { return (attn2_variant() &
 template <> inline float attention_q_scale<f16_t>() { return attention_q_scale<bf16_t>(); }
 template <typename T>
 inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H,
-                                      int N, int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens) {
+                                      int N, int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens, const int* o_row_start) {
     constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
     dim3 grid(Bp * H, (N + 127) / 128);
     const int var = attn2_variant();
@@ -390,7 +393,7 @@ inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, con
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((attn2_fwd_kernel<T, V>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens); \
+        hipLaunchKernelGGL((attn2_fwd_kernel<T, V>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start); \
     }
     if (var == 0) F5_ATTN2_LAUNCH(0)
     else if (var == 3) F5_ATTN2_LAUNCH(3)
@@ -403,16 +406,19 @@ inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, con
 // (kv_lens: key-padding mask, the reference's attn_mask_enabled; q_lens: rows whose output nobody reads; both index
 //  batch row b as lens[b % nbl] and may be null)
 inline hipError_t launch_attention_any(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp,
-                                       int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr) {
-    return launch_attention_v2<bf16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens);
+                                       int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
+                                       const int* o_row_start = nullptr) {
+    return launch_attention_v2<bf16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const f16_t* Q, const f16_t* K, const f16_t* Vt, f16_t* O, int Bp,
-                                       int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr) {
-    return launch_attention_v2<f16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens);
+                                       int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
+                                       const int* o_row_start = nullptr) {
+    return launch_attention_v2<f16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H,
-                                       int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr) {
-    return launch_attention<float>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens);
+                                       int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
+                                       const int* o_row_start = nullptr) {
+    return launch_attention<float>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 
 }  // namespace f5

@@ -12,6 +12,8 @@
 // The im2col row of a token is never materialised: the fragment for k-chunk (tap, ci0) of token t is simply the
 // 16 bytes at LDS row (t + tap), column ci0.
 // Masking (batched inference, modules.py:187-192): tokens >= lens[b] read as zero and produce zero.
+// row_start (RowPack, may be null): batch row b' owns rows row_start[b'] .. row_start[b'+1]-1 of X / res / Y (packed
+// variable-length batch) instead of b' N .. b' N + N - 1; token tiles past that span retire at once.
 #pragma once
 #include "gemm2.h"
 
@@ -21,8 +23,11 @@ template <typename T, int CPG, int NS>
 __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ X, const T* __restrict__ Wp, int Kp,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       float* __restrict__ Y, int N, int D, const int* __restrict__ lens,
-                                                      int nbatch_lens) {
+                                                      int nbatch_lens, const int* __restrict__ row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t rbase = row_start ? (size_t)row_start[blockIdx.z] : (size_t)blockIdx.z * N;   // first row of this batch row
+    const int nrows = row_start ? row_start[blockIdx.z + 1] - row_start[blockIdx.z] : N;        // rows it owns
+    if ((int)blockIdx.x * 128 >= nrows) return;         // (block-uniform, before any barrier)
     constexpr int TM = 128;
     constexpr int XR = TM + 32;                       // rows of the input window kept in LDS
     constexpr int XRB = CPG * sizeof(T);              // bytes per window row
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         const int row = c / (CPG / 4), c4 = c % (CPG / 4);
         const int tok = tok0 - 15 + row;
         float4 v = make_float4(0, 0, 0, 0);
-        if (tok >= 0 && tok < len) v = *reinterpret_cast<const float4*>(X + ((size_t)b * N + tok) * D + grp * CPG + c4 * 4);
+        if (tok >= 0 && tok < len) v = *reinterpret_cast<const float4*>(X + (rbase + tok) * D + grp * CPG + c4 * 4);
         store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, v.x, v.y, v.z, v.w);
     }
     __syncthreads();   // (also retires the window's global loads, which are older than nothing the ring counts below:
@@ -129,10 +134,10 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4*>(bias + grp * CPG + j * 16 + g * 4);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int tokc = min(tok0 + wave * 32 + i * 16 + l15, N - 1);
+        const int tokc = min(tok0 + wave * 32 + i * 16 + l15, nrows - 1);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            rv[i][j] = res ? *reinterpret_cast<const float4*>(res + ((size_t)b * N + tokc) * D + grp * CPG + j * 16 + g * 4)
+            rv[i][j] = res ? *reinterpret_cast<const float4*>(res + (rbase + tokc) * D + grp * CPG + j * 16 + g * 4)
                            : make_float4(0, 0, 0, 0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -145,14 +150,15 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
             float4 v = make_float4(acc[i][j][0] + bi[j].x, acc[i][j][1] + bi[j].y, acc[i][j][2] + bi[j].z, acc[i][j][3] + bi[j].w);
             if (tok >= len) v = make_float4(0, 0, 0, 0);
             v.x = mish(v.x) + rv[i][j].x; v.y = mish(v.y) + rv[i][j].y; v.z = mish(v.z) + rv[i][j].z; v.w = mish(v.w) + rv[i][j].w;
-            if (tok < N) *reinterpret_cast<float4*>(Y + ((size_t)b * N + tok) * D + co) = v;
+            if (tok < nrows) *reinterpret_cast<float4*>(Y + (rbase + tok) * D + co) = v;
         }
     }
 }
 
 template <typename T, int CPG, int NS>
 inline hipError_t launch_convpos_ns(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
-                                    const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+                                    const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl,
+                                    const int* row_start) {
     constexpr int smem = NS * CPG * GEMM_ROW_BYTES + (128 + 32) * (CPG * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -162,29 +168,30 @@ inline hipError_t launch_convpos_ns(hipStream_t s, const float* X, const T* Wp, 
         attr_set = true;
     }
     dim3 grid((N + 127) / 128, D / CPG, Bp);
-    hipLaunchKernelGGL((convpos_kernel<T, CPG, NS>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl);
+    hipLaunchKernelGGL((convpos_kernel<T, CPG, NS>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl, row_start);
     return hipGetLastError();
 }
 
 template <typename T, int CPG>
 inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
-                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl,
+                                     const int* row_start) {
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
     if (Kp % KT != 0) return hipErrorInvalidValue;   // weights must be padded to whole K-tiles
     const long blocks = (long)((N + 127) / 128) * (D / CPG) * Bp;
-    if (blocks > 384) return launch_convpos_ns<T, CPG, 4>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
-    return launch_convpos_ns<T, CPG, 8>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+    if (blocks > 384) return launch_convpos_ns<T, CPG, 4>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+    return launch_convpos_ns<T, CPG, 8>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
 }
 
 // D/16 channels per group must be 16, 32, 48 or 64 (dim 256 / 512 / 768 / 1024).
 template <typename T>
 inline hipError_t launch_convpos(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias, const float* res,
-                                 float* Y, int Bp, int N, int D, const int* lens, int nbl) {
+                                 float* Y, int Bp, int N, int D, const int* lens, int nbl, const int* row_start = nullptr) {
     switch (D / 16) {
-        case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
-        case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
-        case 48: return launch_convpos_cpg<T, 48>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
-        case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl);
+        case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+        case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+        case 48: return launch_convpos_cpg<T, 48>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+        case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
         default: return hipErrorInvalidValue;
     }
 }

@@ -21,10 +21,11 @@ template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out,
                                                         int ldo, int R, int D, float eps, const float* __restrict__ A,
                                                         const float* __restrict__ Bv, int vec_stride,
-                                                        int rows_per_batch, int modulate, Prefetch pf) {
+                                                        int rows_per_batch, int modulate, Prefetch pf,
+                                                        const int* __restrict__ m_limit = nullptr) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
+    if (r >= R || (m_limit && r >= *m_limit)) return;   // (m_limit: rows present in a packed batch, RowPack)
     const float* xr = x + (size_t)r * ldx;
     float4 v[8], ga[8], gb[8];
     // the modulation / affine vectors do not depend on the statistics: request them together with the row so that the
@@ -109,20 +110,26 @@ __global__ __launch_bounds__(256) void xrmsnorm_kernel(const float* __restrict__
 // --------------------------------------------------------------------------------- input-embedding operand
 // A[b', n, :] = [ x[b, n, :mel] | cond[b, n, :mel] (0 for the uncond half / drop_audio_cond) | text[b', n, :Dt] ]
 // (dit.py:135-138, cfg_infer packing dit.py:296-305).  b' in [0, Bp); rows b' >= B are the uncond half.
+// rowmap (RowPack, may be null): output row r is (b', n) = rowmap[r] for r < *row_limit instead of r = b' N + n; rows
+// whose position lies past the sample's own length (the <= 3 alignment rows of a packed utterance) are written as zero.
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ cond,
                                   const float* __restrict__ text_c, const float* __restrict__ text_u,
-                                  T* __restrict__ out, int ldo, int B, int Bp, int N, int mel, int Dt, int drop_cond_first) {
+                                  T* __restrict__ out, int ldo, int B, int Bp, int N, int mel, int Dt, int drop_cond_first,
+                                  const int2* __restrict__ rowmap = nullptr, const int* __restrict__ row_limit = nullptr,
+                                  const int* __restrict__ lens = nullptr) {
     const int K4 = (2 * mel + Dt) / 4;
-    const long total = (long)Bp * N * K4;
+    const long total = (rowmap ? (long)*row_limit : (long)Bp * N) * K4;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % K4) * 4;
         const long row = idx / K4;
-        const int n = (int)(row % N), bp = (int)(row / N);
+        int n = (int)(row % N), bp = (int)(row / N);
+        if (rowmap) { const int2 m = rowmap[row]; bp = m.x; n = m.y; }
         const bool un = bp >= B;
         const int b = un ? bp - B : bp;
         float4 v;
-        if (c < mel) v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + n) * mel + c);
+        if (rowmap && n >= lens[b]) v = make_float4(0, 0, 0, 0);
+        else if (c < mel) v = *reinterpret_cast<const float4*>(x + ((size_t)b * N + n) * mel + c);
         else if (c < 2 * mel)
             v = (un || drop_cond_first) ? make_float4(0, 0, 0, 0)
                                         : *reinterpret_cast<const float4*>(cond + ((size_t)b * N + n) * mel + (c - mel));
@@ -193,6 +200,40 @@ static __global__ void euler_cfg_kernel(float* __restrict__ y, const float* __re
         reinterpret_cast<float4*>(y)[i] = yy;
         if (traj_slot) reinterpret_cast<float4*>(traj_slot)[i] = yy;
     }
+}
+
+// The same update when the backbone ran on PACKED rows (RowPack): pred[r, :] with r = row_start[b'] + n for n < lens[b];
+// frames past a sample's own length keep their value (they influence nothing when attn_mask_enabled, and are not computed).
+static __global__ void euler_cfg_packed_kernel(float* __restrict__ y, const float* __restrict__ pred, int B, int N, int mel,
+                                               const int* __restrict__ row_start, const int* __restrict__ lens,
+                                               const float* __restrict__ tgrid, int step, float cfg, int use_cfg,
+                                               float* __restrict__ traj_slot) {
+    const float dt = tgrid[step + 1] - tgrid[step];
+    const int c4n = mel / 4;
+    const long total = (long)B * N * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n);
+        const long fr = i / c4n;
+        const int n = (int)(fr % N), b = (int)(fr / N);
+        float4 yy = reinterpret_cast<float4*>(y)[i];
+        if (n < lens[b]) {
+            const float4 p = reinterpret_cast<const float4*>(pred + ((size_t)row_start[b] + n) * mel)[c];
+            float4 v = p;
+            if (use_cfg) {
+                const float4 u = reinterpret_cast<const float4*>(pred + ((size_t)row_start[B + b] + n) * mel)[c];
+                v.x = p.x + (p.x - u.x) * cfg; v.y = p.y + (p.y - u.y) * cfg;
+                v.z = p.z + (p.z - u.z) * cfg; v.w = p.w + (p.w - u.w) * cfg;
+            }
+            yy.x += dt * v.x; yy.y += dt * v.y; yy.z += dt * v.z; yy.w += dt * v.w;
+            reinterpret_cast<float4*>(y)[i] = yy;
+        }
+        if (traj_slot) reinterpret_cast<float4*>(traj_slot)[i] = yy;
+    }
+}
+// rowmap[row_start[b'] + n] = (b', n) for n < row_start[b' + 1] - row_start[b']   (one block per batch row)
+static __global__ void fill_rowmap_kernel(const int* __restrict__ row_start, int2* __restrict__ rowmap) {
+    const int bp = blockIdx.x, r0 = row_start[bp], cnt = row_start[bp + 1] - r0;
+    for (int n = threadIdx.x; n < cnt; n += blockDim.x) rowmap[r0 + n] = make_int2(bp, n);
 }
 
 // out = where(mask, a, b) row-wise: cfm.py:151-153 (step_cond) and :221-223 (final out)

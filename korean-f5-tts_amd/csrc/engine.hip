@@ -165,6 +165,14 @@ bool split_cfg_enabled(f5_engine* e) {
     }
     return e->split_cfg == 1;
 }
+// Row packing (RowPack) for DiT batches with attn_mask_enabled: on unless F5_PACK_ROWS=0
+bool pack_rows_enabled(f5_engine* e) {
+    if (e->pack_rows < 0) {
+        const char* v = getenv("F5_PACK_ROWS");
+        e->pack_rows = (v && v[0] == '0') ? 0 : 1;
+    }
+    return e->pack_rows == 1 && e->cfg.attn_mask_enabled && e->cfg.backbone == F5_BACKBONE_DIT && !split_cfg_enabled(e);
+}
 bool graphs_enabled(f5_engine* e) {
     if (e->graphs_on < 0) {
         const char* v = getenv("F5_HIP_GRAPH");

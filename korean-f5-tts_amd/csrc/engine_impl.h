@@ -193,6 +193,8 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.mod = a.take<float>(SS * e->modN);
     w.lens = a.take<int>(Bp + 16);
     w.lens_plain = a.take<int>(Bp + 16);
+    w.row_start = a.take<int>(Bp + (size_t)B + 16);
+    w.rowmap = a.take<int2>(Bp * (size_t)round_up(N, 4));
     w.step_cond = a.take<float>((size_t)B * N * mel);
     w.text_c = a.take<float>((size_t)B * N * Dt);
     w.text_u = a.take<float>((size_t)B * N * Dt);
@@ -314,29 +316,33 @@ static int run_text_embed(f5_engine* e, Work<T>& w, const int64_t* text, int B, 
 template <typename T>
 static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N,
                            const float* mod_row, int mod_stride, const int* lens_dev, int drop_cond_first,
-                           const float* text_first, const float* text_second, hipStream_t s) {
+                           const float* text_first, const float* text_second, hipStream_t s, const RowPack& pk = RowPack{}) {
     Packed<T>& P = packed<T>(e);
     const f5_config& c = e->cfg;
     const int D = c.dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim, H = c.heads;
-    const int rows = Bp * N;
+    const int rows = Bp * N;                        // launch geometry: the padded batch (pk: rows present = *pk.rows_dev)
+    const int* ml = pk.rows_dev;                    // device row count of a packed batch, or null
+    const int* gate_lens = pk ? nullptr : lens_dev; // (a packed batch has no padded rows to leave untouched)
     Prof& pr = e->prof;
-    auto gflops = [&](double n, double k) { return 2.0 * rows * n * k; };
+    const double rows_fl = pk ? pk.rows_host : (double)rows;
+    auto gflops = [&](double n, double k) { return 2.0 * rows_fl * n * k; };
     // input embedding
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL((pack_input_kernel<T>), dim3(ew_blocks((long)rows * e->kin / 4)), dim3(256), 0, s, y, cond,
-                       text_first, text_second, w.acat, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first);
+                       text_first, text_second, w.acat, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first, pk.rowmap, ml,
+                       lens_dev);
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(D, e->kin));
     HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
-                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
+                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}, -1, ml));
     pr.end(s);
-    const double conv_fl = 2.0 * rows * D * (D / 16) * 31;
+    const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);
-    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B));
+    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start));
     pr.end(s);
     pr.begin(PC_CONV, s, conv_fl);
-    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B));
+    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start));
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
@@ -349,44 +355,45 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
                            m + D, m, mod_stride, N, 1,
                            wpf ? Prefetch{(const char*)bw.qkv.w, (size_t)3 * inner * bw.qkv.ldw * sizeof(T),
-                                          (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{});
+                                          (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{}, ml);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>()}));
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
+                              -1, ml));
         pr.end(s);
-        pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)N * N * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev));
+        pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, lens_dev}));
+                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml));
         pr.end(s);
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
                            m + 4 * D, m + 3 * D, mod_stride, N, 1,
                            wpf ? Prefetch{(const char*)bw.ff1.w, (size_t)F * bw.ff1.ldw * sizeof(T),
-                                          (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{});
+                                          (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{}, ml);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(F, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, F));
         HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
-                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}));
+                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml));
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
     pr.begin(PC_LN, s);
     hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f, mf,
-                       mf + D, mod_stride, N, 1, Prefetch{});
+                       mf + D, mod_stride, N, 1, Prefetch{}, ml);
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(mel, D));
     HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
-                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}));
+                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml));
     pr.end(s);
     return F5_OK;
 }
@@ -489,19 +496,19 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
 template <typename T>
 static int run_backbone(f5_engine* e, Work<T>& w, const float* y, const float* cond, int B, int Bp, int N, int step_row,
                         int per_row_time, const int* lens_dev, int drop_cond_first, const float* text_first,
-                        const float* text_second, hipStream_t s) {
+                        const float* text_second, hipStream_t s, const RowPack& pk = RowPack{}) {
     if (e->cfg.backbone == F5_BACKBONE_DIT)
         return run_dit_forward<T>(e, w, y, cond, B, Bp, N, w.mod + (size_t)step_row * e->modN, per_row_time ? e->modN : 0,
-                                  lens_dev, drop_cond_first, text_first, text_second, s);
+                                  lens_dev, drop_cond_first, text_first, text_second, s, pk);
     return run_unett_forward<T>(e, w, y, cond, B, Bp, N, w.temb + (size_t)step_row * e->cfg.dim, per_row_time ? e->cfg.dim : 0,
                                 lens_dev, drop_cond_first, text_first, text_second, s);
 }
 // lens bookkeeping: uploads per-sample lengths (duplicated for the uncond half) through pinned staging
 template <typename T>
 static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, const int32_t* lens_host, int B,
-                        hipStream_t s, int chunk = 0) {
+                        hipStream_t s, int chunk = 0, int halves = 2) {
     if (chunk <= 0 || chunk > B) chunk = B;
-    const size_t bytes = (size_t)nT * 4 + (size_t)3 * B * 4 + 64;
+    const size_t bytes = (size_t)nT * 4 + (size_t)3 * B * 4 + ((size_t)3 * B + 16) * 4 + 64;
     char* hb = nullptr;
     int slot = 0;
     CHK(e->stage.acquire(bytes, &hb, &slot));
@@ -520,6 +527,27 @@ static int upload_small(f5_engine* e, Work<T>& w, const float* t_host, int nT, c
         for (int i = 0; i < B; ++i) lh[2 * B + i] = lens_host[i] + add;
         HIPCHK(hipMemcpyAsync(w.lens, lh, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(w.lens_plain, lh + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        // RowPack tables: per chunk, `halves` x Bc batch rows (cond half, then uncond half), each rounded up to 4 rows;
+        // chunk c's table starts at halves * u0 + c (every chunk has one entry more than it has batch rows)
+        int* rs = lh + 3 * B;
+        e->pack_rows_host.clear();
+        e->pack_sq_host.clear();
+        int cidx = 0, nrs = 0;
+        for (int u0 = 0; u0 < B; u0 += chunk, ++cidx) {
+            const int bc = std::min(chunk, B - u0);
+            int* t = rs + halves * u0 + cidx;
+            double sq = 0;
+            t[0] = 0;
+            for (int k = 0; k < halves * bc; ++k) {
+                const int len = lens_host[u0 + k % bc];
+                t[k + 1] = t[k] + round_up(len, 4);
+                sq += (double)len * len;
+            }
+            e->pack_rows_host.push_back((double)t[halves * bc]);
+            e->pack_sq_host.push_back(sq);
+            nrs = halves * u0 + cidx + halves * bc + 1;
+        }
+        HIPCHK(hipMemcpyAsync(w.row_start, rs, (size_t)nrs * 4, hipMemcpyHostToDevice, s));
     }
     return e->stage.release(slot, s);
 }
@@ -626,6 +654,27 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
         if (!e->ev_join) HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
     const int chunk = chunk_utts(e, B, N, use_cfg);   // (sample_impl laid w.lens out for this chunk size)
+    // packed variable-length batch (RowPack): the row tables of every chunk, built once from the uploaded prefix sums
+    const bool pack = has_lens && pack_rows_enabled(e);
+    const int halves = use_cfg ? 2 : 1;
+    auto chunk_pack = [&](int u0, int cidx, int bc) {
+        RowPack pk;
+        if (!pack) return pk;
+        pk.row_start = w.row_start + halves * u0 + cidx;
+        pk.rowmap = w.rowmap + (size_t)2 * u0 * round_up(N, 4);
+        pk.rows_dev = pk.row_start + halves * bc;
+        if ((size_t)cidx < e->pack_rows_host.size()) { pk.rows_host = e->pack_rows_host[cidx]; pk.sq_host = e->pack_sq_host[cidx]; }
+        return pk;
+    };
+    if (pack) {
+        int cidx = 0;
+        for (int u0 = 0; u0 < B; u0 += chunk, ++cidx) {
+            const int bc = std::min(chunk, B - u0);
+            const RowPack pk = chunk_pack(u0, cidx, bc);
+            hipLaunchKernelGGL(fill_rowmap_kernel, dim3(halves * bc), dim3(256), 0, s, pk.row_start, const_cast<int2*>(pk.rowmap));
+            KCHK();
+        }
+    }
     for (int i = 0; i < steps; ++i) {
         if (split) {
             hipStream_t s1 = e->side_stream;
@@ -643,17 +692,23 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
             e->prof.end(s);
             continue;
         }
-        for (int u0 = 0; u0 < B; u0 += chunk) {
+        int cidx = 0;
+        for (int u0 = 0; u0 < B; u0 += chunk, ++cidx) {
             const int bc = std::min(chunk, B - u0);
             const size_t yo = (size_t)u0 * N * mel, to = (size_t)u0 * N * c.text_dim;
             const long half_c = (long)bc * N * mel;
+            const RowPack pk = chunk_pack(u0, cidx, bc);
             CHK(run_backbone<T>(e, w, w.y + yo, w.step_cond + yo, bc, use_cfg ? 2 * bc : bc, N, i, 0,
                                 lens_dev ? lens_dev + 2 * u0 : nullptr, 0, w.text_c + to,
-                                use_cfg ? w.text_u + to : w.text_c + to, s));
+                                use_cfg ? w.text_u + to : w.text_c + to, s, pk));
             e->prof.begin(PC_MISC, s);
-            hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half_c / 4)), dim3(256), 0, s, w.y + yo, w.pred, half_c, w.tdev, i,
-                               cfg_strength, use_cfg ? 1 : 0,
-                               want_traj ? w.traj_buf + (size_t)(i + 1) * half + yo : nullptr);
+            float* slot = want_traj ? w.traj_buf + (size_t)(i + 1) * half + yo : nullptr;
+            if (pk)
+                hipLaunchKernelGGL(euler_cfg_packed_kernel, dim3(ew_blocks(half_c / 4)), dim3(256), 0, s, w.y + yo, w.pred, bc, N,
+                                   mel, pk.row_start, lens_dev + 2 * u0, w.tdev, i, cfg_strength, use_cfg ? 1 : 0, slot);
+            else
+                hipLaunchKernelGGL(euler_cfg_kernel, dim3(ew_blocks(half_c / 4)), dim3(256), 0, s, w.y + yo, w.pred, half_c, w.tdev,
+                                   i, cfg_strength, use_cfg ? 1 : 0, slot);
             KCHK();
             e->prof.end(s);
         }
@@ -680,7 +735,8 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
     Work<T> w;
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     // ---- inputs -> arena (eager, on the caller's stream)
-    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, chunk_utts(e, B, N, !(cfg_strength < 1e-5f))));
+    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, chunk_utts(e, B, N, !(cfg_strength < 1e-5f)),
+                        cfg_strength < 1e-5f ? 1 : 2));
     if (cond_frames < N) HIPCHK(hipMemsetAsync(w.in_cond, 0, half * sizeof(float), s));   // F.pad(cond, ..., N - cond_seq_len) (cfm.py:145)
     if (cond_frames > 0)
         HIPCHK(hipMemcpy2DAsync(w.in_cond, (size_t)N * mel * sizeof(float), cond, (size_t)cond_frames * mel * sizeof(float),

@@ -200,6 +200,10 @@ struct f5_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int split_cfg = -1;
     int res_nt = 0;
+    // packed variable-length batches (RowPack): per chunk of the last upload, rows present and sum of squared lengths
+    // (host copies, used for the profiler's FLOP counts only) and the switch (F5_PACK_ROWS, default on)
+    std::vector<double> pack_rows_host, pack_sq_host;
+    int pack_rows = -1;
     void clear_graphs() {
         for (auto& g : graphs) {
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -231,6 +235,8 @@ template <typename T> struct Work {
     float *tdev, *feat, *th, *temb, *st, *mod;
     int* lens;        // per-sample lengths, chunk-major: for each chunk of Bc utterances [Bc values][the same Bc values]
     int* lens_plain;  // the same lengths once, in utterance order (text encoder)
+    int* row_start;   // RowPack: per chunk [2 Bc + 1] first packed row of every batch row (cond half, uncond half), last = rows
+    int2* rowmap;     // RowPack: per chunk, packed row -> (batch row, position)
     float *step_cond, *text_c, *text_u, *tx_a, *tx_b, *tx_h1, *grn_part;
     float* uc;        // cached unconditional text embedding [res_N, text_dim] (f5_engine::uc_N)
     unsigned char* dummy;
@@ -248,11 +254,31 @@ template <typename T> struct Work {
     int Npad;
 };
 
+// Row packing of a padded batch.  With attn_mask_enabled (modules.py:501-506) the frames past a sample's own length
+// influence nothing -- the text is embedded per sample (dit.py:247-258), the conv position embedding masks them
+// (modules.py:187-192), they are masked as attention keys and zeroed as attention queries (modules.py:540-542) and every
+// other op is row-wise -- so the backbone runs on the valid rows only, the engine-side equivalent of the reference's
+// unpad_input + flash_attn_varlen_func (modules.py:510-531) and of the TRT runtime's remove_input_padding
+// (f5_tts_trtllm.py:448-456).  Batch row b' owns rows row_start[b'] .. row_start[b'+1]-1 (its length rounded up to a
+// multiple of 4, so that the transposed V^T stores stay 8-byte aligned); q / k / V^T keep their padded per-batch-row layout,
+// so the attention kernel is unchanged apart from where it writes its output rows.  All launch geometry stays that of
+// the PADDED batch and every kernel reads the row count from row_start[Bp] on the device: a captured graph does not
+// depend on the lengths.  ODE state, cond and the trajectory stay padded; frames past a sample's length keep their
+// initial value there (the reference lets them drift: nobody reads them).
+struct RowPack {
+    const int* row_start = nullptr;   // device int[Bp + 1]
+    const int2* rowmap = nullptr;     // device int2[rows]
+    const int* rows_dev = nullptr;    // = row_start + Bp
+    double rows_host = 0, sq_host = 0;
+    explicit operator bool() const { return row_start != nullptr; }
+};
+
 // ------------------------------------------------------------------------------------ shared host helpers (engine.hip)
 int ensure_arena(f5_engine* e, int B, int N, int S);
 int chunk_utts(f5_engine* e, int B, int N, bool use_cfg);
 bool split_cfg_enabled(f5_engine* e);
 bool graphs_enabled(f5_engine* e);
+bool pack_rows_enabled(f5_engine* e);
 
 // Entry points of one operand precision T (float: exact-f32 MFMA; bf16_t / f16_t: 16-bit MFMA operands, f32 accumulate).
 template <typename T> struct EngineOps {

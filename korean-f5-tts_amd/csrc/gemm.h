@@ -143,17 +143,23 @@ struct EpiGateRes {
 // q and k, q pre-scaled by dim_head^-0.5, head split.  q,k -> [B', H, Nseq, 64]; v -> TRANSPOSED [B', H, 64, Npad]
 // (so that both attention B-operands are K-contiguous).  16-column sub-tiles of the V third use the transposed
 // orientation.
+// rowmap (may be null): GEMM row m is (batch row, position) = rowmap[m] (packed variable-length batches, RowPack) instead
+// of (m / Nseq, m % Nseq); every utterance then starts at a multiple of 4 rows, and positions >= Nseq (alignment rows
+// of the longest utterance) are dropped.
 template <typename TO> struct EpiQKV {
     TO* q; TO* k; TO* vt; const float* bias; const float* rope_cos; const float* rope_sin;  // [maxpos][32]
     int Nseq, Npad, H, pe_heads; float q_scale;
-    struct RowCtx { size_t base; const float* cs; const float* sn; };      // base = (b*H*Nseq + pos) * 64
+    const int2* rowmap = nullptr;
+    struct RowCtx { size_t base; const float* cs; const float* sn; };      // base = (b*H*Nseq + pos) * 64; cs == null: drop
     struct ColCtx { float4 b; TO* dst; size_t hoff; int d; bool rot; float scale; };
     struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
     struct TColCtx { float b; size_t hoff; };
     static constexpr bool kTransposes = true;
     __device__ __forceinline__ bool tile_transposed(int n0) const { return n0 >= 2 * H * 64; }
     __device__ __forceinline__ RowCtx row(int m) const {
-        const int b = m / Nseq, pos = m - b * Nseq;
+        int b = m / Nseq, pos = m - b * Nseq;
+        if (rowmap) { const int2 bp = rowmap[m]; b = bp.x; pos = bp.y; }
+        if (pos >= Nseq) return {0, nullptr, nullptr};
         return {((size_t)b * H * Nseq + pos) * 64, rope_cos + pos * 32, rope_sin + pos * 32};
     }
     __device__ __forceinline__ ColCtx col(int n) const {
@@ -164,7 +170,7 @@ template <typename TO> struct EpiQKV {
     }
     struct Pre { float2 cs, sn; };
     __device__ __forceinline__ Pre preload(const RowCtx& r, const ColCtx& c) const {
-        if (!c.rot) return {make_float2(1, 1), make_float2(0, 0)};
+        if (!c.rot || !r.cs) return {make_float2(1, 1), make_float2(0, 0)};
         return {*reinterpret_cast<const float2*>(r.cs + (c.d >> 1)), *reinterpret_cast<const float2*>(r.sn + (c.d >> 1))};
     }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v, const Pre& p) const {
@@ -176,10 +182,14 @@ template <typename TO> struct EpiQKV {
             const float r2 = a2 * cs.y - a3 * sn.y, r3 = a3 * cs.y + a2 * sn.y;
             a0 = r0; a1 = r1; a2 = r2; a3 = r3;
         }
-        store4(c.dst + r.base + c.hoff, a0 * c.scale, a1 * c.scale, a2 * c.scale, a3 * c.scale);
+        if (r.cs) store4(c.dst + r.base + c.hoff, a0 * c.scale, a1 * c.scale, a2 * c.scale, a3 * c.scale);
     }
     __device__ __forceinline__ TRowCtx trow(int m, int M) const {
-        const int b = m / Nseq, pos = m - b * Nseq;
+        int b = m / Nseq, pos = m - b * Nseq;
+        if (rowmap) {   // rows m .. m+3 belong to one utterance (its rows start at a multiple of 4): V^T columns pos .. pos+3 < Npad
+            const int2 bp = rowmap[m];
+            return {(size_t)bp.x * H * 64 * Npad + bp.y, bp.y, bp.x, m + 3 < M, m, M};
+        }
         return {(size_t)b * H * 64 * Npad + pos, pos, b, (pos & 3) == 0 && pos + 3 < Nseq, m, M};
     }
     __device__ __forceinline__ TColCtx tcol(int n) const {
@@ -194,7 +204,8 @@ template <typename TO> struct EpiQKV {
             for (int rr = 0; rr < 4; ++rr) {
                 const int mm = r.m + rr;
                 if (mm < r.M) {
-                    const int bb = mm / Nseq, pp = mm - bb * Nseq;
+                    int bb = mm / Nseq, pp = mm - bb * Nseq;
+                    if (rowmap) { const int2 bp = rowmap[mm]; bb = bp.x; pp = bp.y; }
                     vt[(size_t)bb * H * 64 * Npad + c.hoff + pp] = from_f32<TO>(v[rr] + c.b);
                 }
             }

@@ -71,7 +71,8 @@ __device__ __forceinline__ void wait_row(int kk, int i, u32x4 (&af)[2][MI], u32x
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restrict__ A, int lda, const T* __restrict__ W,
-                                                  int ldw, int M, int N, int K, const Epi& epi, int xa, int xb) {
+                                                  int ldw, int M, int N, int K, const Epi& epi, int xa, int xb,
+                                                  const int* __restrict__ m_limit) {
     constexpr int NW = WM * WN;
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
     constexpr int EPC = 16 / sizeof(T);
@@ -100,6 +101,13 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         tile_n = (rect % rects_n) * xb + in % xb;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // Row count known only on the device (packed variable-length batches, engine_impl.h RowPack): the grid covers the
+    // padded row count so that a captured graph does not depend on the lengths; tiles past the limit retire at once.
+    if (m_limit) {
+        const int ml = __builtin_amdgcn_readfirstlane(*m_limit);
+        if (m0 >= ml) return;
+        M = min(M, ml);
+    }
     const int nkt = K / KT;
     // Orientation per 16-column sub-tile of this wave (wave-uniform).  The transposed columns are a suffix of the output
     // (EpiQKV: the V third), so within a wave they are the LAST nt of its NJ sub-tiles: nt is 0 or NJ except in the one
@@ -324,9 +332,9 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
                                                                    const T* __restrict__ W, int ldw, int M, int N, int K,
-                                                                   Epi epi, int xa, int xb) {
+                                                                   Epi epi, int xa, int xb, const int* __restrict__ m_limit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_tn_glds_body<T, BM, BN, WM, WN, NS, Epi, MODE>(smem, A, lda, W, ldw, M, N, K, epi, xa, xb);
+    gemm_tn_glds_body<T, BM, BN, WM, WN, NS, Epi, MODE>(smem, A, lda, W, ldw, M, N, K, epi, xa, xb, m_limit);
 }
 
 // chooses (xa, xb): tiles_m % xa == 0, tiles_n % xb == 0 and the number of rectangles a multiple of 8; prefers the most
@@ -354,7 +362,7 @@ inline void pick_xcd_rect(int tiles_m, int tiles_n, int* xa, int* xb) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                   const Epi& epi) {
+                                   const Epi& epi, const int* m_limit = nullptr) {
     constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -368,15 +376,15 @@ inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* 
     int xa = 0, xb = 0;
     pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
     hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
-                       ldw, M, N, K, epi, xa, xb);
+                       ldw, M, N, K, epi, xa, xb, m_limit);
     return hipGetLastError();
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                   const Epi& epi) {
+                                   const Epi& epi, const int* m_limit = nullptr) {
     return with_static_act(epi, [&](const auto& e) {
-        return launch_gemm2_raw<T, BM, BN, WM, WN, NS, std::decay_t<decltype(e)>, MODE>(s, A, lda, W, ldw, M, N, K, e);
+        return launch_gemm2_raw<T, BM, BN, WM, WN, NS, std::decay_t<decltype(e)>, MODE>(s, A, lda, W, ldw, M, N, K, e, m_limit);
     });
 }
 

@@ -36,7 +36,7 @@ __device__ __forceinline__ void reg_fence(u32x4& a) { asm volatile("" : "+v"(a))
 
 template <typename T, typename Epi>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw, int M,
-                                                      int N, int K, Epi epi, int xa, int xb) {
+                                                      int N, int K, Epi epi, int xa, int xb, const int* __restrict__ m_limit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 256, BN = 256;
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
@@ -60,6 +60,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
         tile_n = (rect % rects_n) * xb + in % xb;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (m_limit) {                                      // device-side row count (gemm2.h): tiles past it retire at once
+        const int ml = __builtin_amdgcn_readfirstlane(*m_limit);
+        if (m0 >= ml) return;
+        M = min(M, ml);
+    }
     const int nkt = K / KT;
     const bool transposed = Epi::kTransposes && epi.tile_transposed(n0);   // block tiles never straddle the boundary (host check)
 
@@ -273,7 +278,8 @@ template <typename Epi> inline bool gemm3_epilogue_ok(const Epi&) { return !Epi:
 template <typename TO> inline bool gemm3_epilogue_ok(const EpiQKV<TO>& e) { return (2 * e.H * 64) % 256 == 0; }
 
 template <typename T, typename Epi>
-inline hipError_t launch_gemm3_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
+inline hipError_t launch_gemm3_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
+                                   const int* m_limit) {
     constexpr int smem = 2 * 512 * GEMM_ROW_BYTES;   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -285,14 +291,15 @@ inline hipError_t launch_gemm3_raw(hipStream_t s, const T* A, int lda, const T* 
     dim3 grid((N + 255) / 256, (M + 255) / 256);
     int xa = 0, xb = 0;
     pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
-    hipLaunchKernelGGL((gemm_pp_kernel<T, Epi>), grid, dim3(512), smem, s, A, lda, W, ldw, M, N, K, epi, xa, xb);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, Epi>), grid, dim3(512), smem, s, A, lda, W, ldw, M, N, K, epi, xa, xb, m_limit);
     return hipGetLastError();
 }
 
 template <typename T, typename Epi>
-inline hipError_t launch_gemm3(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
+inline hipError_t launch_gemm3(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
+                               const int* m_limit = nullptr) {
     return with_static_act(epi, [&](const auto& e) {
-        return launch_gemm3_raw<T, std::decay_t<decltype(e)>>(s, A, lda, W, ldw, M, N, K, e);
+        return launch_gemm3_raw<T, std::decay_t<decltype(e)>>(s, A, lda, W, ldw, M, N, K, e, m_limit);
     });
 }
 

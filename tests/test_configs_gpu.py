@@ -136,6 +136,33 @@ def test_c3_full_job_properties(monkeypatch):
     assert d < 1e-5
 
 
+def test_c3_attn_mask_packed_rows_match_padded_rows(monkeypatch):
+    """C3 with attn_mask_enabled=True: the engine runs the backbone on the valid rows only (RowPack: the equivalent of the
+    reference's unpad_input + flash_attn_varlen_func, modules.py:510-531).  At Base dims, 16 ragged utterances in two
+    chunks, 2 Euler steps: packed == padded (F5_PACK_ROWS=0, itself pinned against the reference's vectors at small
+    dims) on every frame inside a sample's own length; frames past it keep their initial value."""
+    arch = dict(P.config.F5TTS_BASE, attn_mask_enabled=True)
+    sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
+    gl = torch.Generator().manual_seed(99)
+    durs = [1024] + [int(x) for x in torch.randint(384, 1025, (15,), generator=gl)]
+    cond, text, refs = _ragged_inputs(durs, seed=5)
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, lens=torch.tensor(refs))
+    valid = O.lens_to_mask(torch.tensor(durs), 1024)[..., None].to(DEV)
+    res = {}
+    for prec in ("f32", "bf16"):
+        monkeypatch.setenv("F5_PACK_ROWS", "1")
+        _, tp = _model(P.DiT, arch, sd, prec).sample(cond, text, torch.tensor(durs), **kw)
+        monkeypatch.setenv("F5_PACK_ROWS", "0")
+        _, tu = _model(P.DiT, arch, sd, prec).sample(cond, text, torch.tensor(durs), **kw)
+        res[prec] = ((tp - tu) * valid).abs().max().item()
+        assert torch.isfinite(tp).all()
+        pad = ~valid.expand_as(tp[0])
+        assert torch.equal(tp[-1][pad], tp[0][pad]), "frames past a sample's own length keep their initial value"
+    print(f"[C3 attn_mask, packed vs padded rows, B=16 Base dims] traj Linf on valid frames: f32 {res['f32']:.3e}, bf16 {res['bf16']:.3e}")
+    assert res["f32"] < 2e-5
+    assert res["bf16"] < TOL_C2["bf16"]      # different GEMM tiles / accumulation order at another row count
+
+
 def test_c5_base_unett_batch_vs_oracle():
     """E2-TTS Base backbone (C5's: UNetT, 24 layers, ff_mult 4, N + 1 = 1025 tokens per row), B=8, one Euler step, f32
     against the oracle.  (x_transformers.RMSNorm is restated from memory in both: parity unpinned for that op.)"""
