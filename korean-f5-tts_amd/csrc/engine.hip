@@ -125,10 +125,17 @@ extern "C" int f5_reserve(f5_engine* e, int32_t B, int32_t N, int32_t S) {
 // is stepped in chunks whose activations (x 4 B, xn, q, k, v, ffh 2 B per element: ~17 KB per row) stay inside the 256 MB
 // Infinity Cache between the kernels of a block, instead of streaming every intermediate through HBM (C3: 65,536 rows).
 // F5_CHUNK_ROWS overrides the row budget (tests force tiny chunks).
-int chunk_utts(f5_engine* e, int B, int N, bool use_cfg) {
+// With row packing (RowPack) an utterance costs its own length, not the padded one: the budget then counts the rows
+// actually present (C3: 3 chunks of 11 utterances ~ 15,500 rows instead of 4 x 8 padded to 16,384 of which 11,300 exist).
+int chunk_utts(f5_engine* e, int B, int N, bool use_cfg, const int32_t* lens_host) {
     if (split_cfg_enabled(e)) return B;   // the opt-in two-stream mode steps the whole batch per half
     const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 20000;   // (C3: 4,096 / 8,192 / 16,384 / 32,768 / all rows -> 1.76 / 1.53 / 1.48 / 1.55 / 1.58 s)
-    const long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
+    long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
+    if (lens_host && pack_rows_enabled(e)) {
+        long total = 0;
+        for (int i = 0; i < B; ++i) total += (lens_host[i] + 3) / 4 * 4;
+        rows_per_utt = std::max(1L, (long)(use_cfg ? 2 : 1) * total / B);
+    }
     long bc = budget / rows_per_utt;
     if (bc < 1) bc = 1;
     if (bc >= B) return B;

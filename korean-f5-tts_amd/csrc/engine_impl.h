@@ -322,6 +322,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     const int D = c.dim, F = c.ff_dim, inner = e->inner, mel = c.mel_dim, H = c.heads;
     const int rows = Bp * N;                        // launch geometry: the padded batch (pk: rows present = *pk.rows_dev)
     const int* ml = pk.rows_dev;                    // device row count of a packed batch, or null
+    const int mh = pk ? (int)pk.rows_host : 0;      // rows expected (the call's own lengths): tile choice only
     const int* gate_lens = pk ? nullptr : lens_dev; // (a packed batch has no padded rows to leave untouched)
     Prof& pr = e->prof;
     const double rows_fl = pk ? pk.rows_host : (double)rows;
@@ -335,7 +336,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(D, e->kin));
     HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
-                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}, -1, ml));
+                          EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}, -1, ml, mh));
     pr.end(s);
     const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);
@@ -361,14 +362,14 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
-                              -1, ml));
+                              -1, ml, mh));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml));
+                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml, mh));
         pr.end(s);
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
@@ -378,11 +379,11 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(F, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml));
+        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml, mh));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, F));
         HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
-                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml));
+                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh));
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
@@ -393,7 +394,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(mel, D));
     HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
-                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml));
+                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml, mh));
     pr.end(s);
     return F5_OK;
 }
@@ -653,7 +654,7 @@ static int sample_body(f5_engine* e, Work<T>& w, int nt, int steps, float cfg_st
         if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
         if (!e->ev_join) HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
-    const int chunk = chunk_utts(e, B, N, use_cfg);   // (sample_impl laid w.lens out for this chunk size)
+    const int chunk = e->cur_chunk;   // (chunk_utts, decided by sample_impl, which laid w.lens / w.row_start out for this size)
     // packed variable-length batch (RowPack): the row tables of every chunk, built once from the uploaded prefix sums
     const bool pack = has_lens && pack_rows_enabled(e);
     const int halves = use_cfg ? 2 : 1;
@@ -735,8 +736,8 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
     Work<T> w;
     carve<T>(e, w, e->res_B, e->res_N, e->res_S);
     // ---- inputs -> arena (eager, on the caller's stream)
-    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, chunk_utts(e, B, N, !(cfg_strength < 1e-5f)),
-                        cfg_strength < 1e-5f ? 1 : 2));
+    e->cur_chunk = chunk_utts(e, B, N, !(cfg_strength < 1e-5f), lens_host);
+    CHK(upload_small<T>(e, w, t_host, steps + 1, lens_host, B, s, e->cur_chunk, cfg_strength < 1e-5f ? 1 : 2));
     if (cond_frames < N) HIPCHK(hipMemsetAsync(w.in_cond, 0, half * sizeof(float), s));   // F.pad(cond, ..., N - cond_seq_len) (cfm.py:145)
     if (cond_frames > 0)
         HIPCHK(hipMemcpy2DAsync(w.in_cond, (size_t)N * mel * sizeof(float), cond, (size_t)cond_frames * mel * sizeof(float),
@@ -753,7 +754,7 @@ static int sample_impl(f5_engine* e, const float* cond, int cond_frames, const u
     memcpy(&cfg_bits, &cfg_strength, 4);
     char kb[160];
     snprintf(kb, sizeof(kb), "%d|%d|%d|%d|%08x|%d|%d|%d", B, N, nt, steps, cfg_bits, lens_host ? 1 : 0, traj ? 1 : 0,
-             chunk_utts(e, B, N, use_cfg));
+             e->cur_chunk);
     const std::string base_key(kb);
     const std::string key = base_key + (uc_hit ? "|uc" : "|nouc");
     bool done = false;

@@ -200,6 +200,7 @@ struct f5_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int split_cfg = -1;
     int res_nt = 0;
+    int cur_chunk = 0;   // utterances per backbone call of the sample() in progress (chunk_utts, decided once per call)
     // packed variable-length batches (RowPack): per chunk of the last upload, rows present and sum of squared lengths
     // (host copies, used for the profiler's FLOP counts only) and the switch (F5_PACK_ROWS, default on)
     std::vector<double> pack_rows_host, pack_sq_host;
@@ -275,7 +276,7 @@ struct RowPack {
 
 // ------------------------------------------------------------------------------------ shared host helpers (engine.hip)
 int ensure_arena(f5_engine* e, int B, int N, int S);
-int chunk_utts(f5_engine* e, int B, int N, bool use_cfg);
+int chunk_utts(f5_engine* e, int B, int N, bool use_cfg, const int32_t* lens_host = nullptr);
 bool split_cfg_enabled(f5_engine* e);
 bool graphs_enabled(f5_engine* e);
 bool pack_rows_enabled(f5_engine* e);

@@ -16,6 +16,9 @@ enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_
 // tile that does not add a round wins; e.g. the QKV projection 2048 x 3072: 128x128 = 384 tiles = 2 rounds (25 us),
 // 128x192 = 256 tiles = 1 round (20 us)).
 inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
+    static const int forced = getenv("F5_GEMM_CFG") ? atoi(getenv("F5_GEMM_CFG")) : -1;   // diagnostic: one tile for every GEMM
+    static const int forced_n = getenv("F5_GEMM_CFG_N") ? atoi(getenv("F5_GEMM_CFG_N")) : 0;   // ... only for this N
+    if (forced >= 0 && (forced != G3_256x256_PP || allow_v3) && (forced_n == 0 || forced_n == N)) return forced;
     if (M <= 64) return G2_64x64_4W;  // skinny (time MLP, AdaLN stack over the NFE steps): weight-streaming, no row reuse to gain
     struct Cand { int id, bm, bn; float t; };
     // (256x128: 865 TFLOP/s at M = 16384, N = 2048 against 722 for 128x128: the many-utterance batches C3 / C4)
@@ -50,12 +53,14 @@ inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W,
 // m_limit (device int, may be null): rows actually present, <= M (the v2 / v3 kernels only: the engine's operands always qualify)
 template <typename T, typename Epi>
 inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                              const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr) {
+                              const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0) {
     if (M <= 0 || N <= 0) return hipSuccess;
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
+    // (m_hint: the row count the caller expects behind m_limit -- the tile is chosen for it, the grid covers M)
     if (K % KT == 0 && force_cfg != -2)
         return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi,
-                                      force_cfg >= 0 ? force_cfg : pick_cfg_v2(M, N, sizeof(T) == 2 && gemm3_epilogue_ok(epi)), m_limit);
+                                      force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && gemm3_epilogue_ok(epi)),
+                                      m_limit);
     if (m_limit) return hipErrorInvalidValue;
     return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }

@@ -159,8 +159,10 @@ def test_c3_attn_mask_packed_rows_match_padded_rows(monkeypatch):
         pad = ~valid.expand_as(tp[0])
         assert torch.equal(tp[-1][pad], tp[0][pad]), "frames past a sample's own length keep their initial value"
     print(f"[C3 attn_mask, packed vs padded rows, B=16 Base dims] traj Linf on valid frames: f32 {res['f32']:.3e}, bf16 {res['bf16']:.3e}")
-    assert res["f32"] < 2e-5
-    assert res["bf16"] < TOL_C2["bf16"]      # different GEMM tiles / accumulation order at another row count
+    # bit for bit, in the 16-bit precision too: the packed run steps other chunks (11 + 5 utterances against 8 + 8) through
+    # other GEMM tiles, and a row's result must not depend on either (the library is built with -ffp-contract=off for
+    # exactly this: hipcc's fused multiply-adds differed between instantiations of one epilogue, build.py)
+    assert res["f32"] == 0.0 and res["bf16"] == 0.0
 
 
 def test_c5_base_unett_batch_vs_oracle():
