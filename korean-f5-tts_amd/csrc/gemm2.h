@@ -90,7 +90,17 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // XCD-aware tile order: workgroup ids are dealt round-robin over the 8 XCDs (id % 8 labels the XCD's share); give
     // each share a compact xa x xb rectangle of output tiles so that the A rows / W rows it touches fit its private L2.
     int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (xa > 0) {
+    if (m_limit) {
+        // device-side row count: which row tiles carry work is only known here, so the tile order is the one that spreads
+        // ANY prefix of the row tiles evenly over the XCDs: share x of the round-robin deal owns row tiles x, x + 8, x + 16, ...
+        // with all their column tiles (the launcher rounds the grid up to a multiple of 8 row tiles).  A rectangle
+        // order fixed for the padded grid left the XCDs that own the trailing rectangles idle (-30 % at C3's pad fraction).
+        const int tiles_n = gridDim.x;
+        const int bid = blockIdx.y * tiles_n + blockIdx.x;
+        const int idx = bid >> 3;
+        tile_m = (idx / tiles_n) * 8 + (bid & 7);
+        tile_n = idx % tiles_n;
+    } else if (xa > 0) {
         const int tiles_n = gridDim.x;
         const int bid = blockIdx.y * tiles_n + blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;          // idx-th tile of this XCD's share
@@ -104,9 +114,8 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
     // Row count known only on the device (packed variable-length batches, engine_impl.h RowPack): the grid covers the
     // padded row count so that a captured graph does not depend on the lengths; tiles past the limit retire at once.
     if (m_limit) {
-        const int ml = __builtin_amdgcn_readfirstlane(*m_limit);
-        if (m0 >= ml) return;
-        M = min(M, ml);
+        M = min(M, __builtin_amdgcn_readfirstlane(*m_limit));
+        if (m0 >= M) return;
     }
     const int nkt = K / KT;
     // Orientation per 16-column sub-tile of this wave (wave-uniform).  The transposed columns are a suffix of the output
@@ -372,9 +381,10 @@ inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* 
         attr_set = true;
     }
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    if (m_limit) grid.y = (grid.y + 7) / 8 * 8;   // (the device-side tile order deals row tiles in groups of 8)
     // rectangle of tiles per XCD share: valid only when the grid splits into whole rectangles, 8 at a time
     int xa = 0, xb = 0;
-    pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
+    if (!m_limit) pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
     hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
                        ldw, M, N, K, epi, xa, xb, m_limit);
     return hipGetLastError();

@@ -49,7 +49,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // wr is also the group (0 leads, 1 follows by one barrier)
     int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (xa > 0) {                                       // XCD-aware tile order (gemm2.h)
+    if (m_limit) {                                      // device-side row count: row tiles dealt over the XCDs (gemm2.h)
+        const int tiles_n = gridDim.x;
+        const int bid = blockIdx.y * tiles_n + blockIdx.x;
+        const int idx = bid >> 3;
+        tile_m = (idx / tiles_n) * 8 + (bid & 7);
+        tile_n = idx % tiles_n;
+    } else if (xa > 0) {                                // XCD-aware tile order (gemm2.h)
         const int tiles_n = gridDim.x;
         const int bid = blockIdx.y * tiles_n + blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;
@@ -61,9 +67,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     if (m_limit) {                                      // device-side row count (gemm2.h): tiles past it retire at once
-        const int ml = __builtin_amdgcn_readfirstlane(*m_limit);
-        if (m0 >= ml) return;
-        M = min(M, ml);
+        M = min(M, __builtin_amdgcn_readfirstlane(*m_limit));
+        if (m0 >= M) return;
     }
     const int nkt = K / KT;
     const bool transposed = Epi::kTransposes && epi.tile_transposed(n0);   // block tiles never straddle the boundary (host check)
@@ -289,8 +294,9 @@ inline hipError_t launch_gemm3_raw(hipStream_t s, const T* A, int lda, const T* 
         attr_set = true;
     }
     dim3 grid((N + 255) / 256, (M + 255) / 256);
+    if (m_limit) grid.y = (grid.y + 7) / 8 * 8;   // (the device-side tile order deals row tiles in groups of 8)
     int xa = 0, xb = 0;
-    pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
+    if (!m_limit) pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
     hipLaunchKernelGGL((gemm_pp_kernel<T, Epi>), grid, dim3(512), smem, s, A, lda, W, ldw, M, N, K, epi, xa, xb, m_limit);
     return hipGetLastError();
 }
