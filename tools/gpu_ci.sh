@@ -25,7 +25,7 @@ for st in "$@"; do
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 600 python bench.py --steps 5 --warmup 2 ;;
     bench_nocpu) run bench_nocpu 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
-    prof) run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile ;;
+    prof) run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 ;;
     *) echo "unknown stage $st"; exit 2 ;;
   esac
 done
