@@ -11,7 +11,8 @@
  *   f5_dit_forward   <- DiT.forward / UNetT.forward                  model/backbones/dit.py:278-329, unett.py:217-280
  *   f5_text_embed    <- TextEmbedding.forward (+ per-sample loop)    model/backbones/dit.py:86-115,244-258
  *   f5_vocos_decode  <- vocoder.decode(mel)                          infer/utils_infer.py:702-703 (third-party vocos)
- *   f5_mel_forward   <- MelSpec.forward (vocos type)                 model/modules.py:78-146
+ *   f5_bigvgan_forward <- vocoder(mel) (third-party BigVGAN v2)      infer/utils_infer.py:138-152,705
+ *   f5_mel_forward   <- MelSpec.forward (vocos / bigvgan type)       model/modules.py:33-146
  *   f5_load_weight   <- load_checkpoint's state-dict assignment      infer/utils_infer.py:242-286
  * The reference-side binding (ctypes) is shown in INTEGRATION.md.
  */
@@ -134,6 +135,38 @@ int f5_vocos_decode(f5_vocos* v, const float* mel, int32_t B, int32_t T, float* 
 int f5_vocos_decode_strided(f5_vocos* v, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_c,
                             int64_t stride_t, float* wav, f5_stream stream);
 
+/* ---------------------------------------------------------------------------------------------- BigVGAN
+ * The vocoder of mel_spec_type="bigvgan" (infer/utils_infer.py:138-152: bigvgan.BigVGAN.from_pretrained(
+ * "nvidia/bigvgan_v2_24khz_100band_256x"), remove_weight_norm(); called as vocoder(mel[B, 100, T]) -> wav[B, 1, 256 T]
+ * at :705).  The reference takes it from an un-vendored submodule: the architecture is restated from the published
+ * BigVGAN v2 (see csrc/bigvgan.hip; checker: tests/test_bigvgan.py) -- parity unpinned. */
+typedef struct f5_bigvgan f5_bigvgan;
+typedef struct f5_bigvgan_config {
+    int32_t num_mels;                 /* 100 */
+    int32_t upsample_initial_channel; /* 1536; halves at every upsample stage */
+    int32_t num_upsamples;            /* 6 */
+    int32_t upsample_rates[8];        /* 4, 4, 2, 2, 2, 2 */
+    int32_t upsample_kernel_sizes[8]; /* 8, 8, 4, 4, 4, 4 */
+    int32_t num_kernels;              /* 3 AMP blocks per stage ... */
+    int32_t resblock_kernel_sizes[4]; /* ... with kernels 3, 7, 11 */
+    int32_t num_dilations;            /* 3 (conv, conv) pairs per AMP block ... */
+    int32_t resblock_dilations[4];    /* ... with dilations 1, 3, 5 on the first conv of each pair */
+    int32_t use_tanh_at_final;        /* 0: clamp(-1, 1) */
+    int32_t use_bias_at_final;        /* 0 */
+    int32_t reserved[4];
+} f5_bigvgan_config;
+int f5_bigvgan_create(const f5_bigvgan_config* cfg, f5_bigvgan** out);
+int f5_bigvgan_destroy(f5_bigvgan* v);
+/* names (after remove_weight_norm): conv_pre.{weight,bias}, ups.N.0.{weight,bias}, resblocks.N.convs1.M.{weight,bias},
+ * resblocks.N.convs2.M.{weight,bias}, resblocks.N.activations.A.act.{alpha,beta}, activation_post.act.{alpha,beta},
+ * conv_post.weight (+ .bias); host-computed aux.up_filter / aux.down_filter [12] (kaiser-sinc filters of Activation1d). */
+int f5_bigvgan_load_weight(f5_bigvgan* v, const char* name, const void* dev_f32, const int64_t* shape, int32_t ndim,
+                           f5_stream stream);
+int f5_bigvgan_finalize(f5_bigvgan* v, f5_stream stream);
+/* mel addressed as mel[b * stride_b + c * stride_c + t * stride_t] (element strides) -> wav f32[B, T * prod(rates)] */
+int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, int32_t T, int64_t stride_b, int64_t stride_c,
+                       int64_t stride_t, float* wav, f5_stream stream);
+
 /* ------------------------------------------------------------------------------------- prompt mel front-end
  * MelSpec.forward, mel_spec_type="vocos" (model/modules.py:78-146): wav f32[B, nw] -> log-mel f32[B, T, n_mels],
  * T = nw / hop + 1.  Constant tables are host-computed and loaded once:
@@ -144,6 +177,11 @@ int f5_mel_create(int32_t n_fft, int32_t hop_length, int32_t n_mels, f5_mel** ou
 int f5_mel_destroy(f5_mel* m);
 int f5_mel_load(f5_mel* m, const char* name, const void* dev_f32, const int64_t* shape, int32_t ndim, f5_stream stream);
 int f5_mel_forward(f5_mel* m, const float* wav, int32_t B, int32_t nw, float* out, f5_stream stream);
+/* General form (mel_spec_type="bigvgan", model/modules.py:33-75: pad = (n_fft - hop) / 2, center=False, mag_eps = 1e-9,
+ * aux.mel_fb = librosa's slaney filterbank): reflect padding `pad` on both sides, T = (nw + 2 pad - n_fft) / hop + 1 frames,
+ * |S| = sqrt(re^2 + im^2 + mag_eps).  f5_mel_forward is pad = n_fft / 2, mag_eps = 0. */
+int f5_mel_forward_ex(f5_mel* m, const float* wav, int32_t B, int32_t nw, int32_t pad, float mag_eps, float* out,
+                      f5_stream stream);
 
 /* ----------------------------------------------------------------------------- kernel-level entry points
  * Used by tests/ (parity of each kernel against a torch fp32 restatement) and by the micro-benchmarks.  fp32 in/out;

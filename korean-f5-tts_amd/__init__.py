@@ -5,7 +5,7 @@ for gfx950 in csrc/, reached through the C-ABI declared in include/f5_hip.h (cty
 """
 from . import config, mel, utils, weights  # noqa: F401
 
-__all__ = ["config", "weights", "mel", "utils", "CFM", "DiT", "UNetT", "Vocos", "lib", "infer", "dist", "batching"]
+__all__ = ["config", "weights", "mel", "utils", "CFM", "DiT", "UNetT", "Vocos", "BigVGAN", "lib", "infer", "dist", "batching"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require the built library (CPU-only tooling)
@@ -18,10 +18,13 @@ def __getattr__(name):  # lazy: importing the package must not require the built
     if name == "Vocos":
         from .vocos import Vocos
         return Vocos
+    if name == "BigVGAN":
+        from .bigvgan import BigVGAN
+        return BigVGAN
     if name == "lib":
         from . import _lib
         return _lib
-    if name in ("infer", "dist", "batching", "engine"):
+    if name in ("infer", "dist", "batching", "engine", "bigvgan", "vocos"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

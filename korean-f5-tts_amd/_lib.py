@@ -26,6 +26,13 @@ class f5_config(C.Structure):
         [("reserved", C.c_int32 * 5)]
 
 
+class f5_bigvgan_config(C.Structure):
+    _fields_ = [("num_mels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("num_upsamples", C.c_int32),
+                ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("num_kernels", C.c_int32),
+                ("resblock_kernel_sizes", C.c_int32 * 4), ("num_dilations", C.c_int32), ("resblock_dilations", C.c_int32 * 4),
+                ("use_tanh_at_final", C.c_int32), ("use_bias_at_final", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class f5_vocos_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("input_channels", "dim", "intermediate_dim", "num_layers", "n_fft",
                                          "hop_length")] + [("reserved", C.c_int32 * 4)]
@@ -53,10 +60,16 @@ SIGNATURES = {
     "f5_vocos_finalize": (_i, [_p, _p]),
     "f5_vocos_decode": (_i, [_p, _p, _i, _i, _p, _p]),
     "f5_vocos_decode_strided": (_i, [_p, _p, _i, _i, C.c_int64, C.c_int64, C.c_int64, _p, _p]),
+    "f5_bigvgan_create": (_i, [C.POINTER(f5_bigvgan_config), C.POINTER(_p)]),
+    "f5_bigvgan_destroy": (_i, [_p]),
+    "f5_bigvgan_load_weight": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),
+    "f5_bigvgan_finalize": (_i, [_p, _p]),
+    "f5_bigvgan_forward": (_i, [_p, _p, _i, _i, C.c_int64, C.c_int64, C.c_int64, _p, _p]),
     "f5_mel_create": (_i, [_i, _i, _i, C.POINTER(_p)]),
     "f5_mel_destroy": (_i, [_p]),
     "f5_mel_load": (_i, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _p]),
     "f5_mel_forward": (_i, [_p, _p, _i, _i, _p, _p]),
+    "f5_mel_forward_ex": (_i, [_p, _p, _i, _i, _i, _f, _p, _p]),
     "f5k_gemm": (_i, [_i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "f5k_attention": (_i, [_i, _p, _p, _p, C.POINTER(_i), _p, _i, _i, _i, _p]),
     "f5k_convpos": (_i, [_i, _p, _p, _p, _p, C.POINTER(_i), _p, _i, _i, _i, _p]),

@@ -21,6 +21,14 @@ E2TTS_BASE = dict(dim=1024, depth=24, heads=16, dim_head=64, ff_mult=4, text_mas
 F5TTS_TINY = dict(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, text_dim=64, text_mask_padding=False,
                   conv_layers=2, pe_attn_head=1, attn_mask_enabled=False, qk_norm=None)
 VOCOS_24K = dict(input_channels=100, dim=512, intermediate_dim=1536, num_layers=8, n_fft=1024, hop_length=256)
+# nvidia/bigvgan_v2_24khz_100band_256x (the reference's bigvgan vocoder, infer/utils_infer.py:147-149; config.json of that
+# model as published -- restated from memory)
+BIGVGAN_V2_24K = dict(num_mels=100, upsample_initial_channel=1536, upsample_rates=[4, 4, 2, 2, 2, 2],
+                      upsample_kernel_sizes=[8, 8, 4, 4, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+                      resblock_dilation_sizes=[1, 3, 5], use_tanh_at_final=False, use_bias_at_final=False)
+BIGVGAN_TINY = dict(num_mels=100, upsample_initial_channel=64, upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4],
+                    resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[1, 3, 5], use_tanh_at_final=False,
+                    use_bias_at_final=False)
 VOCOS_TINY = dict(input_channels=100, dim=64, intermediate_dim=192, num_layers=2, n_fft=1024, hop_length=256)
 
 

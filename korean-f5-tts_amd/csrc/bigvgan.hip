@@ -1,0 +1,437 @@
+// BigVGAN v2 generator (mel -> waveform) on gfx950 -- the vocoder of BASELINE config 5 / SURVEY a20, which the reference
+// loads from an un-vendored submodule (infer/utils_infer.py:138-152, called as `vocoder(mel)` at :705; forced to fp32,
+// :332).  PARITY UNPINNED: neither BigVGAN's source nor its weights are in the container; this restates the published
+// architecture of nvidia/bigvgan_v2_24khz_100band_256x (tests/test_bigvgan.py checks the kernels against a CPU
+// restatement of the same published design).  All f32, time-major [L, C] activations (no [B, C, T] permutes), every contraction an exact-f32 MFMA GEMM:
+//   conv_pre            Conv1d(mels, C0, 7)            = im2col (strided mel view) x W[C0, 7 mels]
+//   ups[i]              ConvTranspose1d(C, C/2, k, u)  = GEMM x[L, C] x W'[(tap, co), C]^T -> Z[L, k C/2], then each output
+//                                                        sample gathers its k / u taps from Z (+ bias)
+//   AMPBlock1 convs     Conv1d(C, C, k, dilation d)    = dilated im2col x W[C, k C] with bias (+ residual) epilogues
+//   Activation1d        2x kaiser-sinc upsample -> SnakeBeta -> 2x low-pass downsample, ONE kernel: an output sample needs the
+//                       12 upsampled samples around it, each a 6-tap sum over the input rows t-5 .. t+5 held in registers
+//   conv_post           Conv1d(C_last, 1, 7) + clamp / tanh, direct (168 MACs per sample)
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "elementwise.h"
+#include "gemm_dispatch.h"
+#include "internal.h"
+
+using namespace f5;
+#define fail f5_fail
+
+// ------------------------------------------------------------------------------------------------ kernels
+// A[t][tap * C + c] = x[t + (tap - (k-1)/2) * dil][c]  (zero outside [0, L); columns >= k C zero: K padding of the GEMM)
+static __global__ void bv_im2col_kernel(const float* __restrict__ x, float* __restrict__ A, long L, int C, int k, int dil, int ld) {
+    const int l4 = ld / 4;
+    const long total = L * l4;
+    const int half = (k - 1) / 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % l4) * 4;
+        const long t = i / l4;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (col < k * C) {
+            const int tap = col / C, c = col - tap * C;
+            const long tt = t + (long)(tap - half) * dil;
+            if (tt >= 0 && tt < L) v = *reinterpret_cast<const float4*>(x + tt * C + c);
+        }
+        reinterpret_cast<float4*>(A)[i] = v;
+    }
+}
+
+__device__ __forceinline__ float bv_snake(float v, float a, float invb) {
+    const float s = sinf(v * a);
+    return v + invb * (s * s);
+}
+
+// Activation1d(SnakeBeta) (alias-free activation): y[t] = sum_m fd[m] a[clamp(2t + m - 5, 0, 2L-1)],
+// a[u] = snake(2 sum_{j = (u+1) mod 2 + 2q} fu[j] x[clamp((u + 15 - j) / 2 - 5, 0, L-1)])
+// One thread = one time step x 4 channels.  Interior steps keep the 11 input rows t-5 .. t+5 in registers: upsampled sample
+// m of the 12-window reads row (m / 2 - q + 5) for tap q (static indices).  The few edge steps take the generic path.
+static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restrict__ x, float* __restrict__ y, long L, int C,
+                                                             const float* __restrict__ log_alpha, const float* __restrict__ log_beta,
+                                                             const float* __restrict__ fu, const float* __restrict__ fd) {
+    __shared__ float sfu[12], sfd[12];
+    if (threadIdx.x < 12) { sfu[threadIdx.x] = fu[threadIdx.x]; sfd[threadIdx.x] = fd[threadIdx.x]; }
+    __syncthreads();
+    const int c4n = C / 4;
+    const long total = L * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long t = i / c4n;
+        const float4 la = *reinterpret_cast<const float4*>(log_alpha + c), lb = *reinterpret_cast<const float4*>(log_beta + c);
+        const float a0 = expf(la.x), a1 = expf(la.y), a2 = expf(la.z), a3 = expf(la.w);
+        const float b0 = 1.0f / (expf(lb.x) + 1e-9f), b1 = 1.0f / (expf(lb.y) + 1e-9f), b2 = 1.0f / (expf(lb.z) + 1e-9f),
+                    b3 = 1.0f / (expf(lb.w) + 1e-9f);
+        float4 acc = make_float4(0, 0, 0, 0);
+        if (t >= 3 && t <= L - 4) {
+            float4 r[11];
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                long tt = t - 5 + q;
+                tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
+                r[q] = *reinterpret_cast<const float4*>(x + tt * C + c);
+            }
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                float4 u = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const float f = sfu[(m & 1) + 2 * q];
+                    const float4 v = r[m / 2 - q + 5];
+                    u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+                }
+                const float g = sfd[m];
+                acc.x += g * bv_snake(2.0f * u.x, a0, b0); acc.y += g * bv_snake(2.0f * u.y, a1, b1);
+                acc.z += g * bv_snake(2.0f * u.z, a2, b2); acc.w += g * bv_snake(2.0f * u.w, a3, b3);
+            }
+        } else {
+            for (int m = 0; m < 12; ++m) {
+                long uu = 2 * t + m - 5;
+                uu = uu < 0 ? 0 : (uu > 2 * L - 1 ? 2 * L - 1 : uu);
+                float4 u = make_float4(0, 0, 0, 0);
+                for (int j = (int)((uu + 1) & 1); j < 12; j += 2) {
+                    long tt = (uu + 15 - j) / 2 - 5;
+                    tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
+                    const float f = sfu[j];
+                    const float4 v = *reinterpret_cast<const float4*>(x + tt * C + c);
+                    u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+                }
+                const float g = sfd[m];
+                acc.x += g * bv_snake(2.0f * u.x, a0, b0); acc.y += g * bv_snake(2.0f * u.y, a1, b1);
+                acc.z += g * bv_snake(2.0f * u.z, a2, b2); acc.w += g * bv_snake(2.0f * u.w, a3, b3);
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = acc;
+    }
+}
+
+// ConvTranspose1d tail: y[n][co] = bias[co] + sum_q Z[(n + p - j) / u][j * Co + co], j = (n + p) % u + q u < k, 0 <= (n + p - j) / u < Li
+static __global__ void bv_upsample_gather_kernel(const float* __restrict__ Z, const float* __restrict__ bias, float* __restrict__ y,
+                                                 long Li, int Co, int k, int u, int p) {
+    const int c4n = Co / 4;
+    const long Lo = Li * u;
+    const long total = Lo * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long n = i / c4n;
+        float4 acc = *reinterpret_cast<const float4*>(bias + c);
+        for (int j = (int)((n + p) % u); j < k; j += u) {
+            const long ii = (n + p - j) / u;
+            if (n + p - j >= 0 && ii < Li) {
+                const float4 v = *reinterpret_cast<const float4*>(Z + ii * (long)k * Co + (long)j * Co + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(y)[i] = acc;
+    }
+}
+// x = (r0 + r1 + ... ) / n over n buffers spaced `stride` floats apart  (xs / num_kernels)
+static __global__ void bv_mean_kernel(const float* __restrict__ r, long stride, int n, float* __restrict__ x, long count4) {
+    const float inv = 1.0f / (float)n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count4; i += (long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(r)[i];
+        for (int j = 1; j < n; ++j) {
+            const float4 b = reinterpret_cast<const float4*>(r + j * stride)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(x)[i] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+    }
+}
+// conv_post: wav[t] = clamp / tanh( bias + sum_{tap, c} w[tap * C + c] a[t + tap - 3][c] )
+static __global__ void bv_post_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                      float* __restrict__ wav, long L, int C, int use_tanh) {
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < L; t += (long)gridDim.x * blockDim.x) {
+        float s = bias ? bias[0] : 0.f;
+        for (int tap = 0; tap < 7; ++tap) {
+            const long tt = t + tap - 3;
+            if (tt < 0 || tt >= L) continue;
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a + tt * C + c);
+                const float4 ww = *reinterpret_cast<const float4*>(w + tap * C + c);
+                s += v.x * ww.x; s += v.y * ww.y; s += v.z * ww.z; s += v.w * ww.w;
+            }
+        }
+        wav[t] = use_tanh ? tanhf(s) : fminf(fmaxf(s, -1.0f), 1.0f);
+    }
+}
+// ConvTranspose1d weight [Ci][Co][k] (torch) -> GEMM operand W'[(j * Co + co)][ci]
+static __global__ void bv_pack_convT_kernel(const float* __restrict__ in, float* __restrict__ out, int Ci, int Co, int k, int ld) {
+    const long total = (long)k * Co * ld;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % ld);
+        const long r = i / ld;
+        const int co = (int)(r % Co), j = (int)(r / Co);
+        out[i] = ci < Ci ? in[((long)ci * Co + co) * k + j] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ handle
+namespace {
+struct BT {
+    float* p = nullptr;
+    std::vector<int64_t> shape;
+};
+struct BConv { float *w = nullptr, *b = nullptr; int ld = 0; };          // [Co, ld] tap-major, ld = round_up(k C, 32)
+struct BAct { float *alpha = nullptr, *beta = nullptr; };
+struct BRes { std::vector<BConv> c1, c2; std::vector<BAct> act; int k = 0; };
+struct BUp { float *w = nullptr, *b = nullptr; int ci = 0, co = 0, k = 0, u = 0, ld = 0; };
+}  // namespace
+
+struct f5_bigvgan {
+    f5_bigvgan_config cfg{};
+    std::map<std::string, BT> raw;
+    std::vector<void*> owned;
+    bool finalized = false;
+    BConv pre;
+    int kpre = 0;
+    std::vector<BUp> ups;
+    std::vector<BRes> res;
+    BAct post_act;
+    float *post_w = nullptr, *post_b = nullptr, *fu = nullptr, *fd = nullptr;
+    int c_last = 0, total_up = 1;
+    Arena arena;
+    ~f5_bigvgan() {
+        for (auto& kv : raw)
+            if (kv.second.p) (void)hipFree(kv.second.p);
+        for (void* p : owned) (void)hipFree(p);
+    }
+};
+
+extern "C" int f5_bigvgan_create(const f5_bigvgan_config* c, f5_bigvgan** out) {
+    if (!c || !out) return fail(F5_EINVAL, "f5_bigvgan_create: null argument");
+    if (c->num_upsamples <= 0 || c->num_upsamples > 8 || c->num_kernels <= 0 || c->num_kernels > 4 || c->num_dilations <= 0 ||
+        c->num_dilations > 4 || c->num_mels % 4 || c->upsample_initial_channel % (4 << c->num_upsamples))
+        return fail(F5_EINVAL, "f5_bigvgan_create: unsupported dimensions (channels must stay a multiple of 4 after every halving)");
+    for (int i = 0; i < c->num_upsamples; ++i)
+        if (c->upsample_rates[i] <= 0 || c->upsample_kernel_sizes[i] % c->upsample_rates[i] || (c->upsample_kernel_sizes[i] - c->upsample_rates[i]) % 2)
+            return fail(F5_EINVAL, "f5_bigvgan_create: upsample kernel must be a multiple of its rate and k - u even");
+    for (int j = 0; j < c->num_kernels; ++j)
+        if (c->resblock_kernel_sizes[j] % 2 == 0) return fail(F5_EINVAL, "f5_bigvgan_create: resblock kernels must be odd");
+    f5_bigvgan* v = new f5_bigvgan();
+    v->cfg = *c;
+    v->kpre = round_up(7 * c->num_mels, 32);
+    v->c_last = c->upsample_initial_channel >> c->num_upsamples;
+    for (int i = 0; i < c->num_upsamples; ++i) v->total_up *= c->upsample_rates[i];
+    *out = v;
+    return F5_OK;
+}
+extern "C" int f5_bigvgan_destroy(f5_bigvgan* v) {
+    if (v) {
+        (void)hipDeviceSynchronize();
+        delete v;
+    }
+    return F5_OK;
+}
+extern "C" int f5_bigvgan_load_weight(f5_bigvgan* v, const char* name, const void* dev, const int64_t* shape, int32_t ndim,
+                                      f5_stream stream) {
+    if (!v || !name || !dev || ndim < 0 || ndim > 4) return fail(F5_EINVAL, "f5_bigvgan_load_weight: bad arguments");
+    BT t;
+    t.shape.assign(shape, shape + ndim);
+    size_t n = 1;
+    for (auto d : t.shape) n *= (size_t)d;
+    auto it = v->raw.find(name);
+    if (it != v->raw.end()) {
+        (void)hipFree(it->second.p);
+        v->raw.erase(it);
+    }
+    HIPCHK(hipMalloc((void**)&t.p, std::max<size_t>(n * 4, 16)));
+    HIPCHK(hipMemcpyAsync(t.p, dev, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    v->raw[name] = t;
+    v->finalized = false;
+    return F5_OK;
+}
+
+static int bneed(f5_bigvgan* v, const std::string& n, std::vector<int64_t> shape, const BT** out) {
+    auto it = v->raw.find(n);
+    if (it == v->raw.end()) return fail(F5_ESTATE, "missing bigvgan weight '%s'", n.c_str());
+    if (it->second.shape != shape) return fail(F5_EINVAL, "bigvgan weight '%s' has the wrong shape", n.c_str());
+    *out = &it->second;
+    return F5_OK;
+}
+static int balloc(f5_bigvgan* v, size_t n, float** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(n * 4, 16)));
+    v->owned.push_back(p);
+    *out = (float*)p;
+    return F5_OK;
+}
+static int bcopy(f5_bigvgan* v, hipStream_t s, const std::string& n, std::vector<int64_t> shape, float** out) {
+    const BT* t = nullptr;
+    CHK(bneed(v, n, shape, &t));
+    size_t cnt = 1;
+    for (auto d : shape) cnt *= (size_t)d;
+    CHK(balloc(v, cnt, out));
+    HIPCHK(hipMemcpyAsync(*out, t->p, cnt * 4, hipMemcpyDeviceToDevice, s));
+    return F5_OK;
+}
+// Conv1d weight [Co, Ci, k] (+ bias) -> tap-major GEMM operand [Co, round_up(k Ci, 32)]
+static int bconv(f5_bigvgan* v, hipStream_t s, const std::string& pfx, int Co, int Ci, int k, bool bias, BConv* c) {
+    const BT* t = nullptr;
+    CHK(bneed(v, pfx + ".weight", {Co, Ci, k}, &t));
+    c->ld = round_up(k * Ci, 32);
+    CHK(balloc(v, (size_t)Co * c->ld, &c->w));
+    hipLaunchKernelGGL((conv_pack_kernel<float>), dim3(ew_blocks((long)Co * c->ld)), dim3(256), 0, s, t->p, c->w, (long)Co, Ci, k, c->ld);
+    KCHK();
+    c->b = nullptr;
+    if (bias) CHK(bcopy(v, s, pfx + ".bias", {Co}, &c->b));
+    return F5_OK;
+}
+
+extern "C" int f5_bigvgan_finalize(f5_bigvgan* v, f5_stream stream) {
+    if (!v) return fail(F5_EINVAL, "null bigvgan");
+    hipStream_t s = (hipStream_t)stream;
+    const f5_bigvgan_config& c = v->cfg;
+    for (void* p : v->owned) (void)hipFree(p);
+    v->owned.clear();
+    CHK(bconv(v, s, "conv_pre", c.upsample_initial_channel, c.num_mels, 7, true, &v->pre));
+    v->ups.assign(c.num_upsamples, BUp{});
+    v->res.assign((size_t)c.num_upsamples * c.num_kernels, BRes{});
+    int ch = c.upsample_initial_channel;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        BUp& u = v->ups[i];
+        u.ci = ch; u.co = ch / 2; u.k = c.upsample_kernel_sizes[i]; u.u = c.upsample_rates[i]; u.ld = round_up(ch, 32);
+        const std::string p = "ups." + std::to_string(i) + ".0";
+        const BT* t = nullptr;
+        CHK(bneed(v, p + ".weight", {u.ci, u.co, u.k}, &t));
+        CHK(balloc(v, (size_t)u.k * u.co * u.ld, &u.w));
+        hipLaunchKernelGGL(bv_pack_convT_kernel, dim3(ew_blocks((long)u.k * u.co * u.ld)), dim3(256), 0, s, t->p, u.w, u.ci, u.co, u.k, u.ld);
+        KCHK();
+        CHK(bcopy(v, s, p + ".bias", {u.co}, &u.b));
+        ch /= 2;
+        for (int j = 0; j < c.num_kernels; ++j) {
+            BRes& r = v->res[(size_t)i * c.num_kernels + j];
+            r.k = c.resblock_kernel_sizes[j];
+            const std::string rp = "resblocks." + std::to_string(i * c.num_kernels + j);
+            r.c1.assign(c.num_dilations, BConv{});
+            r.c2.assign(c.num_dilations, BConv{});
+            r.act.assign(2 * c.num_dilations, BAct{});
+            for (int m = 0; m < c.num_dilations; ++m) {
+                CHK(bconv(v, s, rp + ".convs1." + std::to_string(m), ch, ch, r.k, true, &r.c1[m]));
+                CHK(bconv(v, s, rp + ".convs2." + std::to_string(m), ch, ch, r.k, true, &r.c2[m]));
+            }
+            for (int a = 0; a < 2 * c.num_dilations; ++a) {
+                CHK(bcopy(v, s, rp + ".activations." + std::to_string(a) + ".act.alpha", {ch}, &r.act[a].alpha));
+                CHK(bcopy(v, s, rp + ".activations." + std::to_string(a) + ".act.beta", {ch}, &r.act[a].beta));
+            }
+        }
+    }
+    CHK(bcopy(v, s, "activation_post.act.alpha", {v->c_last}, &v->post_act.alpha));
+    CHK(bcopy(v, s, "activation_post.act.beta", {v->c_last}, &v->post_act.beta));
+    {   // conv_post [1, C, 7] -> [7][C]
+        const BT* t = nullptr;
+        CHK(bneed(v, "conv_post.weight", {1, v->c_last, 7}, &t));
+        CHK(balloc(v, (size_t)7 * v->c_last, &v->post_w));
+        hipLaunchKernelGGL((permute_last2_kernel<float>), dim3(ew_blocks(7L * v->c_last)), dim3(256), 0, s, t->p, v->post_w, 1L, v->c_last, 7);
+        KCHK();
+        v->post_b = nullptr;
+        if (c.use_bias_at_final) CHK(bcopy(v, s, "conv_post.bias", {1}, &v->post_b));
+    }
+    CHK(bcopy(v, s, "aux.up_filter", {12}, &v->fu));
+    CHK(bcopy(v, s, "aux.down_filter", {12}, &v->fd));
+    HIPCHK(hipStreamSynchronize(s));
+    for (auto& kv : v->raw)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    v->raw.clear();
+    v->finalized = true;
+    return F5_OK;
+}
+
+// mel f32 addressed as mel[b * sb + c * sc + t * st] (element strides) -> wav f32[B, T * prod(rates)]
+extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, int32_t T, int64_t sb, int64_t sc, int64_t st,
+                                  float* wav, f5_stream stream) {
+    if (!v || !mel || !wav) return fail(F5_EINVAL, "f5_bigvgan_forward: null argument");
+    if (!v->finalized) return fail(F5_ESTATE, "f5_bigvgan_finalize has not been called");
+    if (B <= 0 || T < 1) return fail(F5_EINVAL, "f5_bigvgan_forward: need B >= 1 and T >= 1 frames");
+    hipStream_t s = (hipStream_t)stream;
+    const f5_bigvgan_config& c = v->cfg;
+    // workspace for one utterance (utterances are decoded one after another: a stage's im2col operand is ~200 MB at 8 s)
+    size_t lc_max = (size_t)T * c.upsample_initial_channel, col_max = (size_t)T * v->kpre, z_max = 0;
+    {
+        long L = T;
+        int ch = c.upsample_initial_channel;
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            z_max = std::max(z_max, (size_t)L * c.upsample_kernel_sizes[i] * (ch / 2));
+            L *= c.upsample_rates[i];
+            ch /= 2;
+            lc_max = std::max(lc_max, (size_t)L * ch);
+            for (int j = 0; j < c.num_kernels; ++j) col_max = std::max(col_max, (size_t)L * round_up(c.resblock_kernel_sizes[j] * ch, 32));
+        }
+    }
+    auto plan = [&](Arena& a, float** x, float** r, float** act, float** t1, float** col, float** Z) {
+        a.reset();
+        *x = a.take<float>(lc_max);
+        *r = a.take<float>(lc_max * c.num_kernels);
+        *act = a.take<float>(lc_max);
+        *t1 = a.take<float>(lc_max);
+        *col = a.take<float>(col_max);
+        *Z = a.take<float>(z_max);
+        return align_up(a.off, 256) + 256;
+    };
+    float *x, *r, *act, *t1, *col, *Z;
+    Arena dry;
+    const size_t need_b = plan(dry, &x, &r, &act, &t1, &col, &Z);
+    if (need_b > v->arena.cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (v->arena.base) (void)hipFree(v->arena.base);
+        v->arena.base = nullptr;
+        v->arena.cap = 0;
+        HIPCHK(hipMalloc((void**)&v->arena.base, need_b));
+        v->arena.cap = need_b;
+    }
+    (void)plan(v->arena, &x, &r, &act, &t1, &col, &Z);
+    const long Lout = (long)T * v->total_up;
+    for (int b = 0; b < B; ++b) {
+        long L = T;
+        int ch = c.upsample_initial_channel;
+        // conv_pre
+        hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks((long)T * v->kpre)), dim3(256), 0, s, mel + (size_t)b * sb, 0L, (long)sc, (long)st,
+                           col, 1, c.num_mels, T, v->kpre);
+        KCHK();
+        HIPCHK(launch_gemm<float>(s, col, v->kpre, v->pre.w, v->pre.ld, T, ch, v->kpre, EpiStore<float>{x, ch, v->pre.b, F5_ACT_NONE}));
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            const BUp& u = v->ups[i];
+            // ConvTranspose1d: Z[L, k Co] = x[L, Ci] W'^T, then gather
+            HIPCHK(launch_gemm<float>(s, x, u.ci, u.w, u.ld, (int)L, u.k * u.co, u.ci, EpiStore<float>{Z, u.k * u.co, nullptr, F5_ACT_NONE}));
+            hipLaunchKernelGGL(bv_upsample_gather_kernel, dim3(ew_blocks(L * u.u * (u.co / 4))), dim3(256), 0, s, Z, u.b, x, L, u.co, u.k, u.u,
+                               (u.k - u.u) / 2);
+            KCHK();
+            L *= u.u;
+            ch = u.co;
+            const long cnt = L * ch;
+            for (int j = 0; j < c.num_kernels; ++j) {
+                const BRes& rb = v->res[(size_t)i * c.num_kernels + j];
+                float* rj = r + (size_t)j * lc_max;
+                HIPCHK(hipMemcpyAsync(rj, x, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
+                for (int m = 0; m < c.num_dilations; ++m) {
+                    const int d = c.resblock_dilations[m];
+                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, rj, act, L, ch, rb.act[2 * m].alpha,
+                                       rb.act[2 * m].beta, v->fu, v->fd);
+                    hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (rb.c1[m].ld / 4))), dim3(256), 0, s, act, col, L, ch, rb.k, d,
+                                       rb.c1[m].ld);
+                    KCHK();
+                    HIPCHK(launch_gemm<float>(s, col, rb.c1[m].ld, rb.c1[m].w, rb.c1[m].ld, (int)L, ch, rb.c1[m].ld,
+                                              EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
+                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, t1, act, L, ch, rb.act[2 * m + 1].alpha,
+                                       rb.act[2 * m + 1].beta, v->fu, v->fd);
+                    hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (rb.c2[m].ld / 4))), dim3(256), 0, s, act, col, L, ch, rb.k, 1,
+                                       rb.c2[m].ld);
+                    KCHK();
+                    // x_j = x_j + (conv2(.) + bias): residual epilogue, in place
+                    HIPCHK(launch_gemm<float>(s, col, rb.c2[m].ld, rb.c2[m].w, rb.c2[m].ld, (int)L, ch, rb.c2[m].ld,
+                                              EpiGateRes{rj, rj, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
+                }
+            }
+            hipLaunchKernelGGL(bv_mean_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, r, (long)lc_max, c.num_kernels, x, cnt / 4);
+            KCHK();
+        }
+        hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(L * ch / 4)), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
+                           v->fu, v->fd);
+        hipLaunchKernelGGL(bv_post_kernel, dim3(ew_blocks(L)), dim3(256), 0, s, act, v->post_w, v->post_b, wav + (size_t)b * Lout, L, ch,
+                           c.use_tanh_at_final);
+        KCHK();
+    }
+    return F5_OK;
+}

@@ -6,6 +6,9 @@
 //   |S|   = sqrt(re^2 + im^2)                               (elementwise)
 //   mel   = |S| [T, F(+pad)] x filterbank [n_mels, F(+pad)]^T with a log(max(., 1e-5)) epilogue
 // Output is [B, T, n_mels] -- the layout CFM.sample wants after its permute(0, 2, 1) (cfm.py:106-108).
+// mel_spec_type="bigvgan" (modules.py:33-75, get_bigvgan_mel_spectrogram) is the same pipeline with reflect padding
+// (n_fft - hop) / 2 and center=False (T = (nw + 2 pad - n_fft) / hop + 1), |S| = sqrt(re^2 + im^2 + 1e-9) and librosa's
+// slaney filterbank as the loaded table: f5_mel_forward_ex(pad, eps).
 #include <map>
 #include <string>
 #include <vector>
@@ -33,7 +36,8 @@ static __global__ void reflect_pad_kernel(const float* __restrict__ wav, float* 
     }
 }
 // spec [T, lds] with re in [0, F), im in [F, 2F)  ->  mag [T, ldm], columns >= F zeroed
-static __global__ void magnitude_kernel(const float* __restrict__ spec, int lds, float* __restrict__ mag, int ldm, long T, int F) {
+static __global__ void magnitude_kernel(const float* __restrict__ spec, int lds, float* __restrict__ mag, int ldm, long T, int F,
+                                        float eps) {
     const long total = T * ldm;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % ldm);
@@ -41,7 +45,7 @@ static __global__ void magnitude_kernel(const float* __restrict__ spec, int lds,
         float v = 0.f;
         if (c < F) {
             const float re = spec[t * lds + c], im = spec[t * lds + F + c];
-            v = sqrtf(re * re + im * im);
+            v = sqrtf(re * re + im * im + eps);
         }
         mag[i] = v;
     }
@@ -97,11 +101,18 @@ extern "C" int f5_mel_load(f5_mel* m, const char* name, const void* dev, const i
 }
 // wav f32[B, nw] -> out f32[B, T, n_mels], T = nw / hop + 1 (center=True)
 extern "C" int f5_mel_forward(f5_mel* m, const float* wav, int32_t B, int32_t nw, float* out, f5_stream stream) {
-    if (!m || !wav || !out || B <= 0) return fail(F5_EINVAL, "f5_mel_forward: bad arguments");
+    if (!m) return fail(F5_EINVAL, "f5_mel_forward: bad arguments");
+    return f5_mel_forward_ex(m, wav, B, nw, m->n_fft / 2, 0.0f, out, stream);
+}
+// general form: reflect padding `pad` on both sides, frames at multiples of hop inside the padded signal
+// (T = (nw + 2 pad - n_fft) / hop + 1), magnitude sqrt(re^2 + im^2 + mag_eps)
+extern "C" int f5_mel_forward_ex(f5_mel* m, const float* wav, int32_t B, int32_t nw, int32_t pad, float mag_eps, float* out,
+                                 f5_stream stream) {
+    if (!m || !wav || !out || B <= 0 || pad < 0) return fail(F5_EINVAL, "f5_mel_forward: bad arguments");
     if (!m->basis || !m->fb) return fail(F5_ESTATE, "f5_mel_forward: aux.dft_basis / aux.mel_fb not loaded");
-    if (nw <= m->n_fft / 2) return fail(F5_EINVAL, "f5_mel_forward: need more than n_fft/2 samples for reflect padding");
+    if (nw <= pad || nw + 2 * pad < m->n_fft) return fail(F5_EINVAL, "f5_mel_forward: too few samples for the reflect padding / one frame");
     hipStream_t s = (hipStream_t)stream;
-    const int T = nw / m->hop + 1, pad = m->n_fft / 2, Lp = round_up(nw + 2 * pad, 4);
+    const int T = (nw + 2 * pad - m->n_fft) / m->hop + 1, Lp = round_up(nw + 2 * pad, 4);
     auto plan = [&](Arena& a, float** wp, float** spec, float** mag) {
         a.reset();
         *wp = a.take<float>((size_t)B * Lp + m->n_fft);
@@ -128,7 +139,8 @@ extern "C" int f5_mel_forward(f5_mel* m, const float* wav, int32_t B, int32_t nw
         // frames are a strided view of the padded signal: row t starts at t*hop
         HIPCHK(launch_gemm<float>(s, wp + (size_t)b * Lp, m->hop, m->basis, m->n_fft, T, m->ns, m->n_fft,
                                   EpiStore<float>{spec, m->ns, nullptr, F5_ACT_NONE}));
-        hipLaunchKernelGGL(magnitude_kernel, dim3(ew_blocks((long)T * m->kf)), dim3(256), 0, s, spec, m->ns, mag, m->kf, (long)T, m->F);
+        hipLaunchKernelGGL(magnitude_kernel, dim3(ew_blocks((long)T * m->kf)), dim3(256), 0, s, spec, m->ns, mag, m->kf, (long)T, m->F,
+                           mag_eps);
         KCHK();
         HIPCHK(launch_gemm<float>(s, mag, m->kf, m->fb, m->kf, T, m->n_mels, m->kf,
                                   EpiStore<float>{out + (size_t)b * T * m->n_mels, m->n_mels, nullptr, F5_ACT_LOGCLAMP}));

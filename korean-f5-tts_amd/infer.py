@@ -121,10 +121,18 @@ def load_model(model_cls, model_cfg: dict, ckpt_path: str | None, mel_spec_type=
 
 
 def load_vocoder(vocoder_name="vocos", is_local=True, local_path="", device="cuda", hf_cache_dir=None):
-    if vocoder_name != "vocos":
-        raise NotImplementedError("BigVGAN is an un-vendored submodule of the reference (no source): not built")
+    """utils_infer.py:114-153.  vocos: `pytorch_model.bin` of charactr/vocos-mel-24khz; bigvgan: `bigvgan_generator.pt` of
+    nvidia/bigvgan_v2_24khz_100band_256x ({"generator": state_dict}, weight-norm pairs folded on load)."""
     if not is_local:
-        raise RuntimeError("no network in this environment: pass is_local=True and a directory with pytorch_model.bin")
+        raise RuntimeError("no network in this environment: pass is_local=True and a directory with the vocoder weights")
+    if vocoder_name == "bigvgan":
+        from .bigvgan import BigVGAN
+        voc = BigVGAN()
+        ck = torch.load(f"{local_path}/bigvgan_generator.pt", map_location="cpu", weights_only=True)
+        voc.load_state_dict(ck.get("generator", ck))
+        return voc.eval().to(device)
+    if vocoder_name != "vocos":
+        raise ValueError(f"unknown vocoder {vocoder_name!r}")
     voc = Vocos()
     sd = torch.load(f"{local_path}/pytorch_model.bin", map_location="cpu", weights_only=True)
     voc.load_state_dict(sd)
@@ -186,7 +194,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
             generated, _ = model_obj.sample(cond=a, text=text_list, duration=duration, steps=nfe_step,
                                             cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, seed=seed)
             generated = generated.to(torch.float32)[:, ref_len:, :].permute(0, 2, 1)
-            wave = vocoder.decode(generated)
+            wave = vocoder.decode(generated) if mel_spec_type == "vocos" else vocoder(generated)   # utils_infer.py:702-705
             if rms < target_rms:
                 wave = wave * rms / target_rms
             waves.append(wave.squeeze().cpu().numpy())

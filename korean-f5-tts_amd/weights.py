@@ -127,8 +127,44 @@ def vocos_param_shapes(v: dict) -> dict[str, tuple]:
     return s
 
 
+def bigvgan_param_shapes(v: dict) -> dict[str, tuple]:
+    """Parameter names of BigVGAN v2 (`bigvgan_generator.pt` of nvidia/bigvgan_v2_24khz_100band_256x) after
+    `remove_weight_norm()` (utils_infer.py:151) -- restated from the published model, SURVEY a20."""
+    s: dict[str, tuple] = {}
+    ch = v["upsample_initial_channel"]
+    s["conv_pre.weight"] = (ch, v["num_mels"], 7)
+    s["conv_pre.bias"] = (ch,)
+    nk, nd = len(v["resblock_kernel_sizes"]), len(v["resblock_dilation_sizes"])
+    for i, (u, k) in enumerate(zip(v["upsample_rates"], v["upsample_kernel_sizes"])):
+        s[f"ups.{i}.0.weight"] = (ch, ch // 2, k)      # ConvTranspose1d: [in, out, k]
+        s[f"ups.{i}.0.bias"] = (ch // 2,)
+        ch //= 2
+        for j, rk in enumerate(v["resblock_kernel_sizes"]):
+            p = f"resblocks.{i * nk + j}"
+            for m in range(nd):
+                for cv in ("convs1", "convs2"):
+                    s[f"{p}.{cv}.{m}.weight"] = (ch, ch, rk)
+                    s[f"{p}.{cv}.{m}.bias"] = (ch,)
+            for a in range(2 * nd):
+                s[f"{p}.activations.{a}.act.alpha"] = (ch,)
+                s[f"{p}.activations.{a}.act.beta"] = (ch,)
+    s["activation_post.act.alpha"] = (ch,)
+    s["activation_post.act.beta"] = (ch,)
+    s["conv_post.weight"] = (1, ch, 7)
+    if v.get("use_bias_at_final"):
+        s["conv_post.bias"] = (1,)
+    return s
+
+
 def _std_for(name: str, shape: tuple, std: float) -> tuple[float, float]:
     """(mean, std) per tensor class.  Norm weights ~ 1, layer-scale 1/8-ish, embeddings N(0,1), everything else N(0,std)."""
+    if name.startswith(("conv_pre.", "ups.", "resblocks.", "conv_post.", "activation_post.")):   # BigVGAN: keep the signal O(1)
+        if name.endswith((".alpha", ".beta")):
+            return 0.0, 0.3                            # log-scale SnakeBeta parameters
+        if name.endswith(".weight") and len(shape) == 3:
+            fan = shape[0] * shape[2] / 2 if name.startswith("ups.") else shape[1] * shape[2]
+            return 0.0, float(fan) ** -0.5
+        return 0.0, std
     if name.endswith(".norm.weight") or name.endswith("final_layer_norm.weight") or name.endswith(".g") \
             or name == "backbone.norm.weight":
         return 1.0, 0.05
