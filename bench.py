@@ -200,10 +200,14 @@ def main():
         else:
             arch = dict(P.config.F5TTS_BASE, attn_mask_enabled=bool(args.attn_mask))
             tr_ = P.DiT(**arch, text_num_embeds=nv, mel_dim=100, precision=precision).init_synthetic(seed=0)
-        return tr_, P.CFM(transformer=tr_, mel_spec_module=P.mel.MelSpec()).to(dev)
+        return tr_, P.CFM(transformer=tr_, mel_spec_module=P.mel.MelSpec(mel_spec_type="bigvgan" if args.workload == "c5" else "vocos")).to(dev)
 
     tr, model = build_model(args.precision)
-    voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
+    if args.workload == "c5":   # BASELINE config 5: E2-TTS + BigVGAN (the reference calls it as vocoder(mel), utils_infer.py:705)
+        _bv = P.BigVGAN(P.config.BIGVGAN_V2_24K).init_synthetic(seed=1).to(dev)
+        voc = type("BigVGANDecode", (), {"decode": staticmethod(lambda mel: _bv(mel)), "state_dict": _bv.state_dict})()
+    else:
+        voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
     cond_cpu, text_cpu, durs, refs = make_inputs(P, args, rank)
     # the prompt mel is resident in HBM; the text ids stay on the host (the reference's API takes list[str]: their
     # length feeds host-side duration arithmetic, cfm.py:125-141, and a device copy would force a D2H sync per call)
@@ -278,7 +282,7 @@ def main():
                                 "c3": "C3: F5-TTS Base, %d variable-length utterances/rank/step padded to %d frames (prompt = len/4), "
                                       "NFE=%d, cfg 2.0, sway -1, attn_mask_enabled=%s, per-item Vocos decode" % (B, N, args.nfe, bool(args.attn_mask)),
                                 "c5": "C5: E2-TTS UNetT Base, %d utterances/rank/step, prompt %d + generated %d frames, NFE=%d, cfg 2.0, "
-                                      "sway -1, Vocos decode (BigVGAN is not built)" % (B, ref, gen, args.nfe)}[args.workload],
+                                      "sway -1, BigVGAN v2 decode (24 kHz, 100 band, 256x; parity unpinned)" % (B, ref, gen, args.nfe)}[args.workload],
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }

@@ -163,7 +163,8 @@ def _std_for(name: str, shape: tuple, std: float) -> tuple[float, float]:
             return 0.0, 0.3                            # log-scale SnakeBeta parameters
         if name.endswith(".weight") and len(shape) == 3:
             fan = shape[0] * shape[2] / 2 if name.startswith("ups.") else shape[1] * shape[2]
-            return 0.0, float(fan) ** -0.5
+            gain = 0.35 if name.startswith(("resblocks.", "conv_post.")) else 1.0   # residual branches / output stay small: few clipped samples
+            return 0.0, gain * float(fan) ** -0.5
         return 0.0, std
     if name.endswith(".norm.weight") or name.endswith("final_layer_norm.weight") or name.endswith(".g") \
             or name == "backbone.norm.weight":

@@ -65,7 +65,7 @@ def test_bigvgan_hip_vs_oracle(cfg_name, T, B):
     assert wav.shape == ref.shape
     e = (wav - ref).abs().max().item()
     print(f"[bigvgan f32] {cfg_name} T={T}: wav Linf {e:.3e} (peak {ref.abs().max().item():.3f}, clipped {(ref.abs() >= 1).float().mean().item():.3f})")
-    assert e < 2e-4
+    assert e < 2e-4 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.gpu
