@@ -139,6 +139,34 @@ def load_vocoder(vocoder_name="vocos", is_local=True, local_path="", device="cud
     return voc.eval().to(device)
 
 
+def sinc_resample(waveform: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                  rolloff: float = 0.99) -> torch.Tensor:
+    """torchaudio.transforms.Resample(orig_freq, new_freq) with its defaults (resampling_method="sinc_interp_hann",
+    lowpass_filter_width=6, rolloff=0.99), which the reference applies to prompts that are not at 24 kHz
+    (utils_infer.py:530-532, on the host, before the audio goes to the device).  torchaudio is not installed: this restates
+    its published polyphase windowed-sinc algorithm (functional._get_sinc_resample_kernel / _apply_sinc_resample_kernel)
+    -- PARITY UNPINNED for this step.  waveform f32[c, n] on the host -> f32[c, ceil(n * new / orig)]."""
+    import math
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base_freq / orig)
+    kernels = kernels.to(waveform.dtype)                                       # [new, 1, 2 width + orig]
+    n = waveform.shape[-1]
+    x = torch.nn.functional.pad(waveform.reshape(-1, n), (width, width + orig))
+    y = torch.nn.functional.conv1d(x[:, None], kernels, stride=orig)           # [c, new, frames]
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)[..., : math.ceil(new * n / orig)]
+    return y.reshape(*waveform.shape[:-1], -1)
+
+
 def prompt_numerics(audio: torch.Tensor, sr: int, ref_text: str, gen_text: str, speed_: float = speed,
                     fix_duration_=None, target_rms_: float = target_rms):
     """The host arithmetic of process_batch (utils_infer.py:523-533,541-544,678-685) factored out so that it can be
@@ -149,7 +177,7 @@ def prompt_numerics(audio: torch.Tensor, sr: int, ref_text: str, gen_text: str, 
     if rms < target_rms_:
         audio = audio * target_rms_ / rms
     if sr != target_sample_rate:
-        raise NotImplementedError("resampling needs torchaudio (absent): provide the prompt at 24 kHz")
+        audio = sinc_resample(audio, sr, target_sample_rate)                   # utils_infer.py:530-532
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
     local_speed = 0.3 if len(gen_text.encode("utf-8")) < 10 else speed_

@@ -133,3 +133,28 @@ def test_cfm_state_dict_roundtrip_and_load_model_surface(tmp_path):
         got = model.transformer.state_dict()
         assert all(torch.equal(got[k], sd[k]) for k in sd)
     assert sorted(model.state_dict()) == sorted("transformer." + k for k in sd)
+
+
+def test_sinc_resample_properties():
+    """torchaudio.transforms.Resample restated (parity unpinned: torchaudio is absent).  Properties of the published
+    algorithm: output length ceil(n * new / orig); a sine well below both Nyquists keeps its frequency and amplitude; the
+    identity rate is a no-op; 48 kHz -> 24 kHz removes content above 12 kHz."""
+    import math
+
+    from f5_tts_amd import infer as I
+    n, sr = 16000, 16000
+    t = torch.arange(n, dtype=torch.float32) / sr
+    x = torch.sin(2 * math.pi * 440.0 * t)[None]
+    y = I.sinc_resample(x, sr, 24000)
+    assert y.shape == (1, math.ceil(n * 3 / 2))
+    ref = torch.sin(2 * math.pi * 440.0 * torch.arange(y.shape[1], dtype=torch.float32) / 24000)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3
+    assert I.sinc_resample(x, 24000, 24000) is x
+    t48 = torch.arange(48000, dtype=torch.float32) / 48000
+    hi = torch.sin(2 * math.pi * 18000.0 * t48)[None]
+    lo = torch.sin(2 * math.pi * 3000.0 * t48)[None]
+    assert I.sinc_resample(hi, 48000, 24000)[0, 200:-200].abs().max() < 2e-2
+    assert (I.sinc_resample(lo, 48000, 24000)[0, 200:-200].abs().max() - 1).abs() < 1e-2
+    # the harness takes a prompt at another rate: duration bookkeeping happens on the resampled signal
+    a, rms, rtext, ref_len, dur = I.prompt_numerics(x * 0.5, 16000, "hello there", "general kenobi, you are bold")
+    assert a.shape[-1] == 24000 and ref_len == 24000 // 256
