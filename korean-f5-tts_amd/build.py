@@ -35,20 +35,29 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _digest() -> str:
+def _digest(sources) -> str:
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in list(sources) + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
+def _read(path: str) -> str:
+    try:
+        with open(path) as fh:
+            return fh.read()
+    except OSError:
+        return ""
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compiles the sources whose text (or any header, or the flags) changed since their object was built, then links."""
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(OBJDIR, "digest.txt")
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+    dig = _digest(SOURCES)
+    if not force and os.path.exists(LIB) and _read(stamp) == dig:
         return LIB
     hipcc = _hipcc()
     t0 = time.time()
@@ -57,12 +66,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(obj)
+        sdig = _digest([src])
+        if not force and os.path.exists(obj) and _read(obj + ".digest") == sdig:
+            continue
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        procs.append((src, obj, sdig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, obj, sdig, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        with open(obj + ".digest", "w") as fh:
+            fh.write(sdig)
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
@@ -72,7 +86,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with open(stamp, "w") as fh:
         fh.write(dig)
     if verbose:
-        print(f"built {LIB} in {time.time() - t0:.1f}s")
+        print(f"built {LIB} in {time.time() - t0:.1f}s ({len(procs)} of {len(SOURCES)} sources compiled)")
     return LIB
 
 

@@ -41,15 +41,59 @@ static __global__ void bv_im2col_kernel(const float* __restrict__ x, float* __re
     }
 }
 
+// sin for the snake activation: three-constant Cody-Waite reduction by pi/2 (fma: |x| up to ~1e6 keeps the absolute error
+// at the f32 level) + degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].  Measured against float64 sin over
+// |x| <= 200: max |error| 9.2e-8 (libm's f32 sinf: 6.9e-8).  The library sinf inlines a Payne-Hanek path at each of the
+// activation kernel's call sites (17,000 instructions, 284 registers, one wave per SIMD); this is ~20 instructions.
+__device__ __forceinline__ float bv_sin(float x) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.57079637050628662109375f, x);
+    r = fmaf(-k, -4.371138828673792886547744274139404296875e-8f, r);
+    r = fmaf(-k, -1.7151245100058818728e-15f, r);
+    const int q = (int)k;
+    const float r2 = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2,
+                          fmaf(-0.5f, r2, 1.0f));
+    const float res = (q & 1) ? pc : ps;
+    return (q & 2) ? -res : res;
+}
+
 __device__ __forceinline__ float bv_snake(float v, float a, float invb) {
-    const float s = sinf(v * a);
+    const float s = bv_sin(v * a);
     return v + invb * (s * s);
 }
 
 // Activation1d(SnakeBeta) (alias-free activation): y[t] = sum_m fd[m] a[clamp(2t + m - 5, 0, 2L-1)],
 // a[u] = snake(2 sum_{j = (u+1) mod 2 + 2q} fu[j] x[clamp((u + 15 - j) / 2 - 5, 0, L-1)])
-// One thread = one time step x 4 channels.  Interior steps keep the 11 input rows t-5 .. t+5 in registers: upsampled sample
-// m of the 12-window reads row (m / 2 - q + 5) for tap q (static indices).  The few edge steps take the generic path.
+// One thread = BV_TT consecutive time steps x 4 channels, streamed: the 12 upsampled samples a[2t-5 .. 2t+6] that output t
+// reads live in registers and slide by two per step; the two new ones (u = 2t+5, 2t+6) both read input rows t .. t+5, a
+// six-row register window that slides by one.  Every upsampled sample (one sinf) is so evaluated once per thread instead of
+// once per output that reads it: (10 + 2 BV_TT) / BV_TT evaluations per output instead of 12.
+constexpr int BV_TT = 8;
+
+struct BvSnake { float a0, a1, a2, a3, b0, b1, b2, b3; };
+
+__device__ __forceinline__ float4 bv_snake4(const float4 u, const BvSnake& p) {
+    return make_float4(bv_snake(2.0f * u.x, p.a0, p.b0), bv_snake(2.0f * u.y, p.a1, p.b1), bv_snake(2.0f * u.z, p.a2, p.b2),
+                       bv_snake(2.0f * u.w, p.a3, p.b3));
+}
+
+// a[clamp(u)] from global rows (tile start and sequence edges)
+__device__ __forceinline__ float4 bv_up_generic(const float* __restrict__ x, long u, long L, int C, int c, const float* sfu,
+                                                const BvSnake& p) {
+    u = u < 0 ? 0 : (u > 2 * L - 1 ? 2 * L - 1 : u);
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int j = (int)((u + 1) & 1); j < 12; j += 2) {
+        long tt = (u + 15 - j) / 2 - 5;
+        tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
+        const float f = sfu[j];
+        const float4 v = *reinterpret_cast<const float4*>(x + tt * C + c);
+        s.x += f * v.x; s.y += f * v.y; s.z += f * v.z; s.w += f * v.w;
+    }
+    return bv_snake4(s, p);
+}
+
 static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restrict__ x, float* __restrict__ y, long L, int C,
                                                              const float* __restrict__ log_alpha, const float* __restrict__ log_beta,
                                                              const float* __restrict__ fu, const float* __restrict__ fd) {
@@ -57,54 +101,54 @@ static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restr
     if (threadIdx.x < 12) { sfu[threadIdx.x] = fu[threadIdx.x]; sfd[threadIdx.x] = fd[threadIdx.x]; }
     __syncthreads();
     const int c4n = C / 4;
-    const long total = L * c4n;
+    const long tiles = (L + BV_TT - 1) / BV_TT;
+    const long total = tiles * c4n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
-        const long t = i / c4n;
+        const long t0 = (i / c4n) * BV_TT;
         const float4 la = *reinterpret_cast<const float4*>(log_alpha + c), lb = *reinterpret_cast<const float4*>(log_beta + c);
-        const float a0 = expf(la.x), a1 = expf(la.y), a2 = expf(la.z), a3 = expf(la.w);
-        const float b0 = 1.0f / (expf(lb.x) + 1e-9f), b1 = 1.0f / (expf(lb.y) + 1e-9f), b2 = 1.0f / (expf(lb.z) + 1e-9f),
-                    b3 = 1.0f / (expf(lb.w) + 1e-9f);
-        float4 acc = make_float4(0, 0, 0, 0);
-        if (t >= 3 && t <= L - 4) {
-            float4 r[11];
+        const BvSnake p{expf(la.x), expf(la.y), expf(la.z), expf(la.w), 1.0f / (expf(lb.x) + 1e-9f), 1.0f / (expf(lb.y) + 1e-9f),
+                        1.0f / (expf(lb.z) + 1e-9f), 1.0f / (expf(lb.w) + 1e-9f)};
+        auto row = [&](long tt) {
+            tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
+            return *reinterpret_cast<const float4*>(x + tt * C + c);
+        };
+        float4 a[12], r[6];
 #pragma unroll
-            for (int q = 0; q < 11; ++q) {
-                long tt = t - 5 + q;
-                tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
-                r[q] = *reinterpret_cast<const float4*>(x + tt * C + c);
-            }
+        for (int m = 0; m < 10; ++m) a[m] = bv_up_generic(x, 2 * t0 + m - 5, L, C, c, sfu, p);
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
-                float4 u = make_float4(0, 0, 0, 0);
+        for (int q = 0; q < 6; ++q) r[q] = row(t0 + q);
+#pragma unroll 1
+        for (int k = 0; k < BV_TT; ++k) {
+            const long t = t0 + k;
+            if (t < L) {
+                const float4 nxt = row(t + 6);                     // (issued early: consumed at the end of the step)
+                // u = 2t+5 (odd): taps j = 2q on rows t+5-q;  u = 2t+6 (even): taps j = 2q+1 on the same rows
+                float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    const float f = sfu[(m & 1) + 2 * q];
-                    const float4 v = r[m / 2 - q + 5];
-                    u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+                    const float f0 = sfu[2 * q], f1 = sfu[2 * q + 1];
+                    const float4 v = r[5 - q];
+                    s0.x += f0 * v.x; s0.y += f0 * v.y; s0.z += f0 * v.z; s0.w += f0 * v.w;
+                    s1.x += f1 * v.x; s1.y += f1 * v.y; s1.z += f1 * v.z; s1.w += f1 * v.w;
                 }
-                const float g = sfd[m];
-                acc.x += g * bv_snake(2.0f * u.x, a0, b0); acc.y += g * bv_snake(2.0f * u.y, a1, b1);
-                acc.z += g * bv_snake(2.0f * u.z, a2, b2); acc.w += g * bv_snake(2.0f * u.w, a3, b3);
-            }
-        } else {
-            for (int m = 0; m < 12; ++m) {
-                long uu = 2 * t + m - 5;
-                uu = uu < 0 ? 0 : (uu > 2 * L - 1 ? 2 * L - 1 : uu);
-                float4 u = make_float4(0, 0, 0, 0);
-                for (int j = (int)((uu + 1) & 1); j < 12; j += 2) {
-                    long tt = (uu + 15 - j) / 2 - 5;
-                    tt = tt < 0 ? 0 : (tt > L - 1 ? L - 1 : tt);
-                    const float f = sfu[j];
-                    const float4 v = *reinterpret_cast<const float4*>(x + tt * C + c);
-                    u.x += f * v.x; u.y += f * v.y; u.z += f * v.z; u.w += f * v.w;
+                // past the end a[u] repeats a[2L-1] (replicate padding of the low-pass filter)
+                a[10] = 2 * t + 5 <= 2 * L - 1 ? bv_snake4(s0, p) : a[9];
+                a[11] = 2 * t + 6 <= 2 * L - 1 ? bv_snake4(s1, p) : a[10];
+                float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    const float g = sfd[m];
+                    acc.x += g * a[m].x; acc.y += g * a[m].y; acc.z += g * a[m].z; acc.w += g * a[m].w;
                 }
-                const float g = sfd[m];
-                acc.x += g * bv_snake(2.0f * u.x, a0, b0); acc.y += g * bv_snake(2.0f * u.y, a1, b1);
-                acc.z += g * bv_snake(2.0f * u.z, a2, b2); acc.w += g * bv_snake(2.0f * u.w, a3, b3);
+                *reinterpret_cast<float4*>(y + t * C + c) = acc;
+#pragma unroll
+                for (int m = 0; m < 10; ++m) a[m] = a[m + 2];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) r[q] = r[q + 1];
+                r[5] = nxt;
             }
         }
-        reinterpret_cast<float4*>(y)[i] = acc;
     }
 }
 
@@ -360,11 +404,18 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             for (int j = 0; j < c.num_kernels; ++j) col_max = std::max(col_max, (size_t)L * round_up(c.resblock_kernel_sizes[j] * ch, 32));
         }
     }
+    // Stages whose channel count is a multiple of the f32 K-tile (32) run their dilated convolutions as implicit GEMMs
+    // (GemmConv, gemm2.h) straight off the activation buffer, which then carries `halo` zero rows on both sides; the narrow
+    // last stages (48 / 24 channels in the 24 kHz config) keep the materialised operand.
+    int halo = 0;
+    for (int j = 0; j < c.num_kernels; ++j)
+        for (int m = 0; m < c.num_dilations; ++m) halo = std::max(halo, (c.resblock_kernel_sizes[j] - 1) / 2 * c.resblock_dilations[m]);
+    const bool implicit_ok = !(getenv("F5_BIGVGAN_IMPLICIT") && getenv("F5_BIGVGAN_IMPLICIT")[0] == '0');   // diagnostic: 0 = im2col everywhere
     auto plan = [&](Arena& a, float** x, float** r, float** act, float** t1, float** col, float** Z) {
         a.reset();
         *x = a.take<float>(lc_max);
         *r = a.take<float>(lc_max * c.num_kernels);
-        *act = a.take<float>(lc_max);
+        *act = a.take<float>(lc_max + 2 * (size_t)halo * (c.upsample_initial_channel / 2));
         *t1 = a.take<float>(lc_max);
         *col = a.take<float>(col_max);
         *Z = a.take<float>(z_max);
@@ -401,33 +452,40 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             L *= u.u;
             ch = u.co;
             const long cnt = L * ch;
+            const bool implicit = implicit_ok && ch % 32 == 0;
+            float* acti = act;                      // first activation row
+            if (implicit) {
+                acti = act + (size_t)halo * ch;
+                HIPCHK(hipMemsetAsync(act, 0, (size_t)halo * ch * 4, s));
+                HIPCHK(hipMemsetAsync(acti + cnt, 0, (size_t)halo * ch * 4, s));
+            }
+            auto conv = [&](const BConv& cw, int k, int d, const auto& epi) -> hipError_t {
+                if (implicit) return launch_gemm<float>(s, acti, ch, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0,
+                                                        GemmConv{ch / 32, d, (k - 1) / 2});
+                hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (cw.ld / 4))), dim3(256), 0, s, acti, col, L, ch, k, d, cw.ld);
+                return launch_gemm<float>(s, col, cw.ld, cw.w, cw.ld, (int)L, ch, cw.ld, epi);
+            };
             for (int j = 0; j < c.num_kernels; ++j) {
                 const BRes& rb = v->res[(size_t)i * c.num_kernels + j];
                 float* rj = r + (size_t)j * lc_max;
                 HIPCHK(hipMemcpyAsync(rj, x, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
                 for (int m = 0; m < c.num_dilations; ++m) {
                     const int d = c.resblock_dilations[m];
-                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, rj, act, L, ch, rb.act[2 * m].alpha,
+                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rj, acti, L, ch, rb.act[2 * m].alpha,
                                        rb.act[2 * m].beta, v->fu, v->fd);
-                    hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (rb.c1[m].ld / 4))), dim3(256), 0, s, act, col, L, ch, rb.k, d,
-                                       rb.c1[m].ld);
                     KCHK();
-                    HIPCHK(launch_gemm<float>(s, col, rb.c1[m].ld, rb.c1[m].w, rb.c1[m].ld, (int)L, ch, rb.c1[m].ld,
-                                              EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
-                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, t1, act, L, ch, rb.act[2 * m + 1].alpha,
+                    HIPCHK(conv(rb.c1[m], rb.k, d, EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
+                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, t1, acti, L, ch, rb.act[2 * m + 1].alpha,
                                        rb.act[2 * m + 1].beta, v->fu, v->fd);
-                    hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (rb.c2[m].ld / 4))), dim3(256), 0, s, act, col, L, ch, rb.k, 1,
-                                       rb.c2[m].ld);
                     KCHK();
                     // x_j = x_j + (conv2(.) + bias): residual epilogue, in place
-                    HIPCHK(launch_gemm<float>(s, col, rb.c2[m].ld, rb.c2[m].w, rb.c2[m].ld, (int)L, ch, rb.c2[m].ld,
-                                              EpiGateRes{rj, rj, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
+                    HIPCHK(conv(rb.c2[m], rb.k, 1, EpiGateRes{rj, rj, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
                 }
             }
             hipLaunchKernelGGL(bv_mean_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, r, (long)lc_max, c.num_kernels, x, cnt / 4);
             KCHK();
         }
-        hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks(L * ch / 4)), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
+        hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
                            v->fu, v->fd);
         hipLaunchKernelGGL(bv_post_kernel, dim3(ew_blocks(L)), dim3(256), 0, s, act, v->post_w, v->post_b, wav + (size_t)b * Lout, L, ch,
                            c.use_tanh_at_final);
@@ -435,3 +493,4 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
     }
     return F5_OK;
 }
+

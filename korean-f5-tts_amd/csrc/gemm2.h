@@ -69,10 +69,16 @@ __device__ __forceinline__ void wait_row(int kk, int i, u32x4 (&af)[2][MI], u32x
 #undef F5_WR
 }
 
+// Implicit-GEMM Conv1d over a time-major [rows, C] activation (BigVGAN's dilated convolutions, bigvgan.hip): K index
+// tap * C + ci of the tap-major weight operand multiplies A[row + (tap - half) * dil][ci], so K-tile kt of the A operand
+// starts (kt / tpt - half) * dil ROWS away and at column (kt % tpt) * KT -- no im2col operand is materialised.  The caller
+// pads the activation with half * dil zero rows on both sides.  tpt = K-tiles per tap (C / KT); tpt == 0: plain GEMM.
+struct GemmConv { int tpt = 0, dil = 0, half = 0; };
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restrict__ A, int lda, const T* __restrict__ W,
                                                   int ldw, int M, int N, int K, const Epi& epi, int xa, int xb,
-                                                  const int* __restrict__ m_limit) {
+                                                  const int* __restrict__ m_limit, const GemmConv cv = GemmConv{}) {
     constexpr int NW = WM * WN;
     constexpr int KT = GEMM_ROW_BYTES / sizeof(T);
     constexpr int EPC = 16 / sizeof(T);
@@ -144,8 +150,8 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         const int row = min(n0 + (wave + i * NW) * 8 + lr, N - 1);
         wsrc[i] = W + (size_t)row * ldw + lc * EPC;
     }
-    auto issue_piece = [&](int p, int koff, char* base) {  // p is a compile-time constant after unrolling
-        if (p < LA) glds16(asrc[p] + koff, base + (wave + p * NW) * 1024);
+    auto issue_piece = [&](int p, long akoff, int koff, char* base) {  // p is a compile-time constant after unrolling
+        if (p < LA) glds16(asrc[p] + akoff, base + (wave + p * NW) * 1024);
         else glds16(wsrc[p - LA] + koff, base + BM * GEMM_ROW_BYTES + (wave + (p - LA) * NW) * 1024);
     };
     // (tiles past the end are never requested: a dummy tail load would have to be waited for before the workgroup may
@@ -154,8 +160,13 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
         if (kt >= nkt) return;
         char* base = smem + stage * STAGE;
         const int koff = kt * KT;
+        long akoff = koff;
+        if (cv.tpt > 0) {                               // implicit conv: this K-tile's tap shifts the A rows
+            const int tap = kt / cv.tpt;
+            akoff = (long)(tap - cv.half) * cv.dil * lda + (long)(kt - tap * cv.tpt) * KT;
+        }
 #pragma unroll
-        for (int p = 0; p < L; ++p) issue_piece(p, koff, base);
+        for (int p = 0; p < L; ++p) issue_piece(p, akoff, koff, base);
     };
     // wait until at most `tiles` (<= NS-2) of this wave's requested tiles are still in flight
     auto wait_tiles = [&](int tiles) {
@@ -341,9 +352,10 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_tn_glds_kernel(const T* __restrict__ A, int lda,
                                                                    const T* __restrict__ W, int ldw, int M, int N, int K,
-                                                                   Epi epi, int xa, int xb, const int* __restrict__ m_limit) {
+                                                                   Epi epi, int xa, int xb, const int* __restrict__ m_limit,
+                                                                   const GemmConv cv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_tn_glds_body<T, BM, BN, WM, WN, NS, Epi, MODE>(smem, A, lda, W, ldw, M, N, K, epi, xa, xb, m_limit);
+    gemm_tn_glds_body<T, BM, BN, WM, WN, NS, Epi, MODE>(smem, A, lda, W, ldw, M, N, K, epi, xa, xb, m_limit, cv);
 }
 
 // chooses (xa, xb): tiles_m % xa == 0, tiles_n % xb == 0 and the number of rectangles a multiple of 8; prefers the most
@@ -371,7 +383,7 @@ inline void pick_xcd_rect(int tiles_m, int tiles_n, int* xa, int* xb) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                   const Epi& epi, const int* m_limit = nullptr) {
+                                   const Epi& epi, const int* m_limit = nullptr, const GemmConv& cv = GemmConv{}) {
     constexpr int smem = NS * (BM + BN) * GEMM_ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -386,15 +398,15 @@ inline hipError_t launch_gemm2_raw(hipStream_t s, const T* A, int lda, const T* 
     int xa = 0, xb = 0;
     if (!m_limit) pick_xcd_rect((int)grid.y, (int)grid.x, &xa, &xb);
     hipLaunchKernelGGL((gemm_tn_glds_kernel<T, BM, BN, WM, WN, NS, Epi, MODE>), grid, dim3(WM * WN * 64), smem, s, A, lda, W,
-                       ldw, M, N, K, epi, xa, xb, m_limit);
+                       ldw, M, N, K, epi, xa, xb, m_limit, cv);
     return hipGetLastError();
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 inline hipError_t launch_gemm2_cfg(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                   const Epi& epi, const int* m_limit = nullptr) {
+                                   const Epi& epi, const int* m_limit = nullptr, const GemmConv& cv = GemmConv{}) {
     return with_static_act(epi, [&](const auto& e) {
-        return launch_gemm2_raw<T, BM, BN, WM, WN, NS, std::decay_t<decltype(e)>, MODE>(s, A, lda, W, ldw, M, N, K, e, m_limit);
+        return launch_gemm2_raw<T, BM, BN, WM, WN, NS, std::decay_t<decltype(e)>, MODE>(s, A, lda, W, ldw, M, N, K, e, m_limit, cv);
     });
 }
 

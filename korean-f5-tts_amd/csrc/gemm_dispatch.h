@@ -39,28 +39,30 @@ inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
 
 template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                 const Epi& epi, int cfg, const int* ml = nullptr) {
+                                 const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}) {
     switch (cfg) {
-        case G3_256x256_PP: return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
-        case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
-        case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
-        case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
-        case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
-        default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
+        case G3_256x256_PP: if (cv.tpt == 0) return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);   // (no conv mode: falls through)
+        case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+        case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+        case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+        case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+        default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
     }
 }
 
 // m_limit (device int, may be null): rows actually present, <= M (the v2 / v3 kernels only: the engine's operands always qualify)
 template <typename T, typename Epi>
 inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                              const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0) {
+                              const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0,
+                              const GemmConv& cv = GemmConv{}) {
     if (M <= 0 || N <= 0) return hipSuccess;
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
+    if (cv.tpt > 0 && (K % KT != 0 || force_cfg == -2)) return hipErrorInvalidValue;   // implicit conv: v2 kernels only
     // (m_hint: the row count the caller expects behind m_limit -- the tile is chosen for it, the grid covers M)
     if (K % KT == 0 && force_cfg != -2)
         return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi,
-                                      force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && gemm3_epilogue_ok(epi)),
-                                      m_limit);
+                                      force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi)),
+                                      m_limit, cv);
     if (m_limit) return hipErrorInvalidValue;
     return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }

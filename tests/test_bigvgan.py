@@ -81,6 +81,19 @@ def test_bigvgan_full_size_runs_and_is_deterministic():
 
 
 @pytest.mark.gpu
+def test_bigvgan_implicit_conv_equals_materialised_operand(monkeypatch):
+    """The implicit-GEMM convolutions (GemmConv: K-tiles read shifted rows of the zero-haloed activation) accumulate the same
+    products in the same order as the im2col GEMMs they replace: bit-identical waveforms (all kernel sizes and dilations)."""
+    cfg = dict(P.config.BIGVGAN_V2_24K, upsample_initial_channel=256)
+    voc = P.BigVGAN(cfg).init_synthetic(seed=5).to("cuda:0")
+    mel = torch.randn(1, 100, 31, generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    w_imp = voc(mel).clone()
+    monkeypatch.setenv("F5_BIGVGAN_IMPLICIT", "0")
+    w_mat = voc(mel)
+    assert torch.equal(w_imp, w_mat)
+
+
+@pytest.mark.gpu
 def test_bigvgan_mel_variant_vs_oracle():
     """mel_spec_type="bigvgan" (model/modules.py:33-75) on the HIP front-end against the restatement of those lines."""
     g = torch.Generator().manual_seed(4)
