@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x3": 2500.0 / 3}   # (f16x3: three f16 MFMAs per product)  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f16x3", "f32"])
     ap.add_argument("--nfe", type=int, default=16)
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--ref-frames", type=int, default=256)
@@ -377,7 +377,7 @@ def main():
         ref_out, ref_traj = ref_model.sample(cond, text, dur_t, lens=lens_t, **kw)
         torch.cuda.synchronize()
         precs = {}
-        for prec in ("f32", "f16", "bf16"):
+        for prec in ("f32", "f16x3", "f16", "bf16"):
             m = model if prec == args.precision else (ref_model if prec == "f32" else build_model(prec)[1])
             for _ in range(3):   # arena growth, graph capture, clocks
                 step(m)

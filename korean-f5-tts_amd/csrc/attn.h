@@ -221,4 +221,260 @@ inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const 
     return hipGetLastError();
 }
 
+
+// ---- F5_PREC_F16X3: f32 in / f32 out, both products on the f16 matrix pipe with split operands ----------------------------
+// Same transposed formulation as above with the 16-bit fragment layouts (32-deep f16 MFMA steps).  Every operand x is used as
+// x_hi + x_lo (x_hi = f16(x), x_lo = f16(x - x_hi); the matrix pipe keeps f16 subnormals) and every product as
+// hi*hi + lo*hi + hi*lo accumulated in f32:
+//   Q   split once per block into registers (the same 32 registers the f32 fragments took);
+//   K,V split by the thread that stages them: global f32 chunk -> two 8-byte LDS writes into an f16 hi plane and an f16 lo plane
+//       (the four planes of a tile take the bytes of the two f32 images they replace);
+//   P   (the softmax numerators, f32 accumulators) split in registers into the B operand of V^T P^T.
+// 6 + 6 sixteen-cycle MFMAs per (16 keys x 16 queries x 64) instead of 16 + 16 thirty-two-cycle f32 ones.
+__device__ __forceinline__ void split4_f16(const u32x4& c, u32x2& hi, u32x2& lo) {
+    typedef __attribute__((ext_vector_type(2))) float v2f;
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2h;
+    const f32x4 x = __builtin_bit_cast(f32x4, c);
+    const v2f a{x[0], x[1]}, b{x[2], x[3]};
+    const v2h ah = __builtin_convertvector(a, v2h), bh = __builtin_convertvector(b, v2h);
+    const v2h al = __builtin_convertvector(a - __builtin_convertvector(ah, v2f), v2h);
+    const v2h bl = __builtin_convertvector(b - __builtin_convertvector(bh, v2f), v2h);
+    hi = u32x2{__builtin_bit_cast(unsigned, ah), __builtin_bit_cast(unsigned, bh)};
+    lo = u32x2{__builtin_bit_cast(unsigned, al), __builtin_bit_cast(unsigned, bl)};
+}
+__device__ __forceinline__ f32x4 mma_h(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int QS>
+static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ Vt, float* __restrict__ O, int H, int N,
+                                                             int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
+                                                             const int* __restrict__ q_lens, const int* __restrict__ o_row_start) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (q_lens && (int)blockIdx.x * (64 * QS) >= q_lens[blockIdx.z % nbatch_lens]) return;
+    constexpr int RS = 128 + 16;                // f16 plane row: 64 elements + pad
+    constexpr int PLANE = 64 * RS;
+    constexpr int BUF = 4 * PLANE;              // K hi, K lo, V hi, V lo
+    constexpr float L2E = 1.4426950408889634f;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const size_t bh = (size_t)b * H + h;
+    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
+    int kv_len = N;
+    if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
+    const int nkt = (kv_len + 63) / 64;
+
+    // Q fragments: step f (32 dims) wants dims f*32 + g*8 .. +7 of row q
+    u32x4 qh[QS][2], ql[QS][2];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        const int q = q0 + qs * 16 + l15;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            u32x4 c0{0u, 0u, 0u, 0u}, c1{0u, 0u, 0u, 0u};
+            if (q < N) {
+                const float* src = Q + (bh * N + q) * 64 + f * 32 + g * 8;
+                c0 = *reinterpret_cast<const u32x4*>(src);
+                c1 = *reinterpret_cast<const u32x4*>(src + 4);
+            }
+            u32x2 h0, l0, h1, l1;
+            split4_f16(c0, h0, l0);
+            split4_f16(c1, h1, l1);
+            qh[qs][f] = u32x4{h0.x, h0.y, h1.x, h1.y};
+            ql[qs][f] = u32x4{l0.x, l0.y, l1.x, l1.y};
+        }
+    }
+
+    // staging: 64 rows x 16 four-float chunks per operand per tile = 4 chunks per thread
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, row = c >> 4, cc = c & 15;
+            const int key = kt * 64 + row;
+            rk[i] = key < N ? *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * 4) : u32x4{0u, 0u, 0u, 0u};
+            rv[i] = *reinterpret_cast<const u32x4*>(Vt + (bh * 64 + row) * Npad + kt * 64 + cc * 4);
+        }
+    };
+    auto sstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, row = c >> 4, cc = c & 15;
+            u32x2 hi, lo;
+            split4_f16(rk[i], hi, lo);
+            *reinterpret_cast<u32x2*>(base + row * RS + cc * 8) = hi;
+            *reinterpret_cast<u32x2*>(base + PLANE + row * RS + cc * 8) = lo;
+            split4_f16(rv[i], hi, lo);
+            *reinterpret_cast<u32x2*>(base + 2 * PLANE + row * RS + cc * 8) = hi;
+            *reinterpret_cast<u32x2*>(base + 3 * PLANE + row * RS + cc * 8) = lo;
+        }
+    };
+
+    f32x4 o[4][QS];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) o[dt][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[QS], lrun[QS];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) { mrun[qs] = -1e30f; lrun[qs] = 0.f; }
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload(kt + 1);
+        const char* Ks = smem + (kt & 1) * BUF + l15 * RS + g * 16;
+        const char* Vs = smem + (kt & 1) * BUF + 2 * PLANE + l15 * RS;
+
+        // ---- S^T = K Q^T
+        f32x4 s[4][QS];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (term-major over the 8 accumulators of a step: a dependent MFMA would wait out its predecessor's whole pipeline)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            u32x4 kh[4], kl[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kh[ks] = *reinterpret_cast<const u32x4*>(Ks + ks * 16 * RS + f * 64);
+                kl[ks] = *reinterpret_cast<const u32x4*>(Ks + PLANE + ks * 16 * RS + f * 64);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs)
+                        s[ks][qs] = mma_h(term == 0 ? kl[ks] : kh[ks], term == 1 ? ql[qs][f] : qh[qs][f], s[ks][qs]);
+        }
+
+        // ---- online softmax (per q column = per lane)
+        // (the tile that straddles kv_len -- the last one -- masks its tail in a branch of its own: masked scores sit 1e30 below
+        //  the row maximum, which a valid key of the same tile sets, so their numerators come out as exact zeros;
+        //  v_exp_f32 directly: every argument is <= 0, a flushed denormal numerator is a zero that does not matter)
+        const int key_base = kt * 64 + g * 4;
+        if (kt * 64 + 64 > kv_len) {
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_base + ks * 16 + r >= kv_len) s[ks][qs][r] = -1e30f;
+        }
+#pragma unroll
+        for (int qs = 0; qs < QS; ++qs) {
+            float mloc = -1e30f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[ks][qs][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mnew = fmaxf(mrun[qs], mloc);
+            const float alpha = __builtin_amdgcn_exp2f((mrun[qs] - mnew) * L2E);
+            mrun[qs] = mnew;
+            const float mb = mnew * L2E;
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[ks][qs][r] * L2E - mb);
+                    s[ks][qs][r] = p;
+                    psum += p;
+                }
+            lrun[qs] = lrun[qs] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt][qs][0] *= alpha; o[dt][qs][1] *= alpha; o[dt][qs][2] *= alpha; o[dt][qs][3] *= alpha;
+            }
+        }
+
+        // ---- O^T += V^T P^T : the 8 k-slots of a 32-key step = keys {4g..4g+3} of two adjacent 16-key sub-tiles
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            u32x4 ph[QS], pl[QS];
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+                u32x2 h0, l0, h1, l1;
+                split4_f16(__builtin_bit_cast(u32x4, s[2 * kp][qs]), h0, l0);
+                split4_f16(__builtin_bit_cast(u32x4, s[2 * kp + 1][qs]), h1, l1);
+                ph[qs] = u32x4{h0.x, h0.y, h1.x, h1.y};
+                pl[qs] = u32x4{l0.x, l0.y, l1.x, l1.y};
+            }
+            u32x4 vh[4], vl[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vrow = Vs + dt * 16 * RS + (32 * kp + 4 * g) * 2;
+                const u32x2 a0 = *reinterpret_cast<const u32x2*>(vrow), a1 = *reinterpret_cast<const u32x2*>(vrow + 32);
+                const u32x2 b0 = *reinterpret_cast<const u32x2*>(vrow + PLANE), b1 = *reinterpret_cast<const u32x2*>(vrow + PLANE + 32);
+                vh[dt] = u32x4{a0.x, a0.y, a1.x, a1.y};
+                vl[dt] = u32x4{b0.x, b0.y, b1.x, b1.y};
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int qs = 0; qs < QS; ++qs)
+                        o[dt][qs] = mma_h(term == 0 ? vl[dt] : vh[dt], term == 1 ? pl[qs] : ph[qs], o[dt][qs]);
+        }
+
+        if (kt + 1 < nkt) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        float l = lrun[qs];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qs * 16 + l15;
+        const size_t orow = o_row_start ? (size_t)o_row_start[b] + q : (size_t)b * N + q;
+        if (q < (o_row_start ? min(N, o_row_start[b + 1] - o_row_start[b]) : N)) {
+            float* dst = O + orow * (H * 64) + h * 64 + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                store4(dst + dt * 16, o[dt][qs][0] * inv, o[dt][qs][1] * inv, o[dt][qs][2] * inv, o[dt][qs][3] * inv);
+        }
+    }
+}
+
+inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
+                                         int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
+                                         const int* o_row_start = nullptr) {
+    constexpr int smem = 2 * 4 * 64 * (128 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    // 128-query blocks (32 per wave) when they alone fill the chip twice over; else 64-query blocks: twice the workgroups, so that
+    // a SIMD has a second wave to overlap the softmax / split arithmetic of one with the MFMAs of the other
+    static const int forced = getenv("F5_ATTN_SPLIT_QS") ? atoi(getenv("F5_ATTN_SPLIT_QS")) : 0;
+    const long blocks128 = (long)((N + 127) / 128) * H * Bp;
+    const int qs = forced ? forced : (blocks128 >= 512 ? 2 : 1);
+    if (qs == 2) {
+        dim3 grid((N + 127) / 128, H, Bp);
+        hipLaunchKernelGGL(attn_split_fwd_kernel<2>, grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
+    } else {
+        dim3 grid((N + 63) / 64, H, Bp);
+        hipLaunchKernelGGL(attn_split_fwd_kernel<1>, grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace f5

@@ -152,6 +152,116 @@ static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restr
     }
 }
 
+// Conv1d(C, C, k, dilation) for the NARROW last stages (C < 64: 48 and 24 channels in the 24 kHz config, where a GEMM tile
+// would be mostly padding and the im2col operand ~200 MB).  One workgroup = 4 waves = 64 MT time steps x all channels:
+//   - the input rows [t0 - halo, t0 + TB + halo) are staged once in LDS (row stride C + 1 words: the 16 rows x 2 columns a
+//     half-wave reads at once fall in distinct banks), zero outside [0, L): every tap re-reads them shifted, no im2col;
+//   - v_mfma_f32_16x16x4_f32 with the WEIGHT as first operand: lane (lr = lane % 16, lk = lane / 16) feeds W[n = 16 nt + lr]
+//     [K = 4 kk + lk] and x[t = m0 + lr + shift(tap)][ci = 4 cs + lk], and ends with out[t = m0 + lr][n = 16 nt + 4 lk .. + 3]
+//     -- a float4 of channels per lane for the bias / residual / store;
+//   - the weights are pre-packed [K / 4][NT][64 lanes] (bv_pack_narrow_kernel) so a fragment is one coalesced 256-byte
+//     load, requested one k-step ahead of its use (all workgroups read the same <= 100 KB: L1/L2 hits).
+typedef float bv_f32x4 __attribute__((ext_vector_type(4)));
+
+static __global__ void bv_pack_narrow_kernel(const float* __restrict__ w /*[Co][ld] tap-major*/, float* __restrict__ wn, int Co, int ld,
+                                             int K, int NT) {
+    const long total = (long)(K / 4) * NT * 64;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), lr = lane & 15, lk = lane >> 4;
+        const long f = i >> 6;
+        const int nt = (int)(f % NT), kk = (int)(f / NT);
+        const int n = nt * 16 + lr;
+        wn[i] = n < Co ? w[(long)n * ld + kk * 4 + lk] : 0.0f;
+    }
+}
+
+template <int NT, int MT>
+static __global__ __launch_bounds__(256) void bv_conv_narrow_kernel(const float* __restrict__ x, const float* __restrict__ wn,
+                                                                     const float* __restrict__ bias, const float* res, float* out,
+                                                                     long L, int C, int k, int dil) {
+    extern __shared__ float bv_xs[];
+    constexpr int TB = 4 * MT * 16;
+    const int half = (k - 1) / 2, halo = half * dil, S = C + 1, rows = TB + 2 * halo, c4n = C / 4;
+    const long t0 = (long)blockIdx.x * TB;
+    for (int i = threadIdx.x; i < rows * c4n; i += 256) {
+        const int row = i / c4n, col = (i - row * c4n) * 4;
+        const long g = t0 - halo + row;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (g >= 0 && g < L) v = *reinterpret_cast<const float4*>(x + g * C + col);
+        float* d = bv_xs + row * S + col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+    bv_f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bv_f32x4{0, 0, 0, 0};
+    const float* wl = wn + lane;
+    const float* xl = bv_xs + (wave * MT * 16 + lr + halo) * S + lk;
+    const int total = k * c4n;
+    float b[NT], bn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = wl[nt * 64];
+    int kk = 0;
+    for (int tap = 0; tap < k; ++tap) {
+        const float* xt = xl + (tap - half) * dil * S;
+        for (int cs = 0; cs < c4n; ++cs, ++kk) {
+            const int kn = min(kk + 1, total - 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = wl[(long)(kn * NT + nt) * 64];
+            float a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = xt[mt * 16 * S + cs * 4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt], a[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long t = t0 + (wave * MT + mt) * 16 + lr;
+        if (t >= L) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + 4 * lk;
+            if (n >= C) continue;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            float4 o = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+            if (res) {
+                const float4 rv = *reinterpret_cast<const float4*>(res + t * C + n);
+                o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+            }
+            *reinterpret_cast<float4*>(out + t * C + n) = o;
+        }
+    }
+}
+
+constexpr int BV_NARROW_MT = 2;
+static hipError_t launch_conv_narrow(hipStream_t s, const float* x, const float* wn, const float* bias, const float* res, float* out,
+                                     long L, int C, int k, int dil) {
+    constexpr int MT = BV_NARROW_MT, TB = 4 * MT * 16;
+    const int NT = (C + 15) / 16;
+    const size_t smem = (size_t)(TB + (k - 1) * dil) * (C + 1) * 4;
+    const dim3 grid((unsigned)((L + TB - 1) / TB)), block(256);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((bv_conv_narrow_kernel<1, MT>), grid, block, smem, s, x, wn, bias, res, out, L, C, k, dil); break;
+        case 2: hipLaunchKernelGGL((bv_conv_narrow_kernel<2, MT>), grid, block, smem, s, x, wn, bias, res, out, L, C, k, dil); break;
+        case 3: hipLaunchKernelGGL((bv_conv_narrow_kernel<3, MT>), grid, block, smem, s, x, wn, bias, res, out, L, C, k, dil); break;
+        case 4: hipLaunchKernelGGL((bv_conv_narrow_kernel<4, MT>), grid, block, smem, s, x, wn, bias, res, out, L, C, k, dil); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// the narrow kernel's LDS tile must fit the default 64 KB dynamic limit
+static bool conv_narrow_ok(int C, int k, int dil) {
+    return C % 4 == 0 && C < 64 && (size_t)(4 * BV_NARROW_MT * 16 + (k - 1) * dil) * (C + 1) * 4 <= 64 * 1024;
+}
+
 // ConvTranspose1d tail: y[n][co] = bias[co] + sum_q Z[(n + p - j) / u][j * Co + co], j = (n + p) % u + q u < k, 0 <= (n + p - j) / u < Li
 static __global__ void bv_upsample_gather_kernel(const float* __restrict__ Z, const float* __restrict__ bias, float* __restrict__ y,
                                                  long Li, int Co, int k, int u, int p) {
@@ -218,7 +328,7 @@ struct BT {
     float* p = nullptr;
     std::vector<int64_t> shape;
 };
-struct BConv { float *w = nullptr, *b = nullptr; int ld = 0; };          // [Co, ld] tap-major, ld = round_up(k C, 32)
+struct BConv { float *w = nullptr, *b = nullptr, *wn = nullptr; int ld = 0; };   // wn: bv_pack_narrow_kernel layout (C < 64 only)          // [Co, ld] tap-major, ld = round_up(k C, 32)
 struct BAct { float *alpha = nullptr, *beta = nullptr; };
 struct BRes { std::vector<BConv> c1, c2; std::vector<BAct> act; int k = 0; };
 struct BUp { float *w = nullptr, *b = nullptr; int ci = 0, co = 0, k = 0, u = 0, ld = 0; };
@@ -321,8 +431,20 @@ static int bconv(f5_bigvgan* v, hipStream_t s, const std::string& pfx, int Co, i
     KCHK();
     c->b = nullptr;
     if (bias) CHK(bcopy(v, s, pfx + ".bias", {Co}, &c->b));
+    c->wn = nullptr;
+    if (Co == Ci && Ci % 4 == 0 && Ci < 64 && bias) {
+        const int NT = (Co + 15) / 16, K = k * Ci;
+        CHK(balloc(v, (size_t)(K / 4) * NT * 64, &c->wn));
+        hipLaunchKernelGGL(bv_pack_narrow_kernel, dim3(ew_blocks((long)(K / 4) * NT * 64)), dim3(256), 0, s, c->w, c->wn, Co, c->ld, K, NT);
+        KCHK();
+    }
     return F5_OK;
 }
+
+static const float* epi_res(const EpiStore<float>&) { return nullptr; }
+static float* epi_out(const EpiStore<float>& e) { return e.out; }
+static const float* epi_res(const EpiGateRes& e) { return e.res; }
+static float* epi_out(const EpiGateRes& e) { return e.x; }
 
 extern "C" int f5_bigvgan_finalize(f5_bigvgan* v, f5_stream stream) {
     if (!v) return fail(F5_EINVAL, "null bigvgan");
@@ -410,6 +532,7 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
     int halo = 0;
     for (int j = 0; j < c.num_kernels; ++j)
         for (int m = 0; m < c.num_dilations; ++m) halo = std::max(halo, (c.resblock_kernel_sizes[j] - 1) / 2 * c.resblock_dilations[m]);
+    const bool narrow_ok = !(getenv("F5_BIGVGAN_NARROW") && getenv("F5_BIGVGAN_NARROW")[0] == '0');         // diagnostic: 0 = GEMM path for C < 64
     const bool implicit_ok = !(getenv("F5_BIGVGAN_IMPLICIT") && getenv("F5_BIGVGAN_IMPLICIT")[0] == '0');   // diagnostic: 0 = im2col everywhere
     auto plan = [&](Arena& a, float** x, float** r, float** act, float** t1, float** col, float** Z) {
         a.reset();
@@ -460,6 +583,8 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
                 HIPCHK(hipMemsetAsync(acti + cnt, 0, (size_t)halo * ch * 4, s));
             }
             auto conv = [&](const BConv& cw, int k, int d, const auto& epi) -> hipError_t {
+                if (narrow_ok && cw.wn && conv_narrow_ok(ch, k, d))
+                    return launch_conv_narrow(s, acti, cw.wn, cw.b, epi_res(epi), epi_out(epi), L, ch, k, d);
                 if (implicit) return launch_gemm<float>(s, acti, ch, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0,
                                                         GemmConv{ch / 32, d, (k - 1) / 2});
                 hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (cw.ld / 4))), dim3(256), 0, s, acti, col, L, ch, k, d, cw.ld);

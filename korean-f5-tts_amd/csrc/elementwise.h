@@ -529,6 +529,39 @@ static __global__ void istft_ola_kernel(const float* __restrict__ frames, const 
     }
 }
 
+// In place: W f32 [rows, ld] (ld % 32 == 0) -> per 32-element block the 128 bytes the split-operand GEMM reads (gemm2.h MODE 3):
+// 16-byte chunk g = f16 hi of k = 4g..4g+3, 16+4g..16+4g+3; chunk 4 + g = f16 lo (w - hi) of the same k.  One thread per block.
+static __global__ void split_planar_kernel(float* __restrict__ w, long blocks) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < blocks; i += (long)gridDim.x * blockDim.x) {
+        float4* p = reinterpret_cast<float4*>(w + i * 32);
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 t = p[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        f16_t hi[32], lo[32];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float x = v[(s < 4 ? 4 * g : 16 + 4 * g - 4) + s];
+                const f16_t h = (f16_t)x;
+                hi[g * 8 + s] = h;
+                lo[g * 8 + s] = (f16_t)(x - (float)h);
+            }
+        f16x8* o = reinterpret_cast<f16x8*>(w + i * 32);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x8 a, b;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { a[s] = hi[g * 8 + s]; b[s] = lo[g * 8 + s]; }
+            o[g] = a;
+            o[4 + g] = b;
+        }
+    }
+}
+
 inline int ew_blocks(long total, int per_block = 256, int cap = 4096) {
     long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;

@@ -45,7 +45,8 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     if (c->heads <= 0 || (c->heads * 64) % 64 != 0 || c->depth <= 0) return fail(F5_EINVAL, "bad heads/depth");
     if (c->mel_dim % 4 || c->text_dim % 4 || c->ff_dim % 8) return fail(F5_EINVAL, "mel_dim/text_dim %% 4, ff_dim %% 8 required");
     if ((2 * c->mel_dim + c->text_dim) % 4) return fail(F5_EINVAL, "2*mel_dim + text_dim must be a multiple of 4");
-    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16 && c->precision != F5_PREC_F16) return fail(F5_EINVAL, "bad precision");
+    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16 && c->precision != F5_PREC_F16 && c->precision != F5_PREC_F16X3)
+        return fail(F5_EINVAL, "bad precision");
     if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return fail(F5_EINVAL, "bad backbone");
     if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2)) return fail(F5_EINVAL, "UNetT depth must be even");
     if (c->text_dim > 2048 || c->dim > 2048) return fail(F5_EINVAL, "dims > 2048 unsupported");
@@ -55,6 +56,7 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     e->kin = 2 * c->mel_dim + c->text_dim;
     e->kin_pad = round_up(e->kin, 64);  // whole 128-byte K-tiles for the LDS-DMA GEMM (pad columns stay zero)
     e->modN = (6 * c->depth + 2) * c->dim;
+    e->split16 = c->precision == F5_PREC_F16X3;
     *out = e;
     return F5_OK;
 }

@@ -18,8 +18,25 @@ static int need(const WeightStore& ws, const std::string& n, std::initializer_li
     return F5_OK;
 }
 
+// F5_PREC_F16X3: the backbone's GEMM weights (BB) are stored split into f16 hi / lo halves (elementwise.h split_planar_kernel)
+template <typename T, bool BB> static int maybe_split_weight(f5_engine* e, hipStream_t s, T* w, size_t elems) {
+    if constexpr (BB && std::is_same_v<T, float>) {
+        if (e->split16) {
+            hipLaunchKernelGGL(split_planar_kernel, dim3(ew_blocks((long)(elems / 32))), dim3(256), 0, s, w, (long)(elems / 32));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return F5_OK;
+}
+// every backbone GEMM goes through here (the time / text paths call launch_gemm<float> directly: always plain f32)
+template <typename T, typename Epi>
+static hipError_t egemm(const f5_engine* e, hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
+                        int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0) {
+    return launch_gemm<T>(s, A, lda, W, ldw, M, N, K, epi, force_cfg, m_limit, m_hint, GemmConv{}, std::is_same_v<T, float> && e->split16);
+}
+
 // W [N, K] f32 -> T [N, round_up(K, 8)]
-template <typename T>
+template <typename T, bool BB = false>
 static int pack_linear(f5_engine* e, hipStream_t s, const std::string& wname, const std::string& bname, int N, int K,
                        LinW<T>* L, int n_pad = 0) {
     const Tensor *w = nullptr, *b = nullptr;
@@ -38,11 +55,11 @@ static int pack_linear(f5_engine* e, hipStream_t s, const std::string& wname, co
         hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(ew_blocks(Np)), dim3(256), 0, s, b->p, N, 1, N, L->b, Np, 1);
     }
     HIPCHK(hipGetLastError());
-    return F5_OK;
+    return maybe_split_weight<T, BB>(e, s, L->w, (size_t)Np * L->ldw);
 }
 
 // concatenates several [Ni, K] linears row-wise into one [sum Ni, ldw] operand (+ bias)
-template <typename T>
+template <typename T, bool BB = false>
 static int pack_concat(f5_engine* e, hipStream_t s, const std::vector<std::string>& pfx, int Ni, int K, LinW<T>* L,
                        bool bias = true) {
     const int n = (int)pfx.size();
@@ -63,8 +80,12 @@ static int pack_concat(f5_engine* e, hipStream_t s, const std::vector<std::strin
         }
     }
     HIPCHK(hipGetLastError());
-    return F5_OK;
+    return maybe_split_weight<T, BB>(e, s, L->w, (size_t)L->N * L->ldw);
 }
+
+// the backbone's own GEMM weights (split in F5_PREC_F16X3)
+template <typename T, typename... Args> static int pack_linear_bb(Args&&... args) { return pack_linear<T, true>(std::forward<Args>(args)...); }
+template <typename T, typename... Args> static int pack_concat_bb(Args&&... args) { return pack_concat<T, true>(std::forward<Args>(args)...); }
 
 static int copy_vec(f5_engine* e, hipStream_t s, const std::string& name, std::initializer_list<int64_t> shape,
                     float** out) {
@@ -116,7 +137,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         CHK(pack_linear<float>(e, s, p + ".pwconv2.weight", p + ".pwconv2.bias", Dt, 2 * Dt, &tb.pw2));
     }
     // input embedding
-    CHK(pack_linear<T>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj));
+    CHK(pack_linear_bb<T>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj));
     const int cpg = D / 16;
     P.conv_kp = round_up(31 * cpg, GEMM_ROW_BYTES / (int)sizeof(T));   // whole K-tiles, zero padded (convpos.h)
     for (int j = 0; j < 2; ++j) {
@@ -136,17 +157,17 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         const std::string p = dit ? "transformer_blocks." + std::to_string(i) : "layers." + std::to_string(i);
         const std::string at = dit ? p + ".attn" : p + ".2";
         const std::string ff = dit ? p + ".ff" : p + ".4";
-        CHK(pack_concat<T>(e, s, {at + ".to_q", at + ".to_k", at + ".to_v"}, inner, D, &b.qkv));
-        CHK(pack_linear<T>(e, s, at + ".to_out.0.weight", at + ".to_out.0.bias", D, inner, &b.out));
-        CHK(pack_linear<T>(e, s, ff + ".ff.0.0.weight", ff + ".ff.0.0.bias", F, D, &b.ff1));
-        CHK(pack_linear<T>(e, s, ff + ".ff.2.weight", ff + ".ff.2.bias", D, F, &b.ff2));
+        CHK(pack_concat_bb<T>(e, s, std::vector<std::string>{at + ".to_q", at + ".to_k", at + ".to_v"}, inner, D, &b.qkv));
+        CHK(pack_linear_bb<T>(e, s, at + ".to_out.0.weight", at + ".to_out.0.bias", D, inner, &b.out));
+        CHK(pack_linear_bb<T>(e, s, ff + ".ff.0.0.weight", ff + ".ff.0.0.bias", F, D, &b.ff1));
+        CHK(pack_linear_bb<T>(e, s, ff + ".ff.2.weight", ff + ".ff.2.bias", D, F, &b.ff2));
         if (dit) {
             modp.push_back(p + ".attn_norm.linear");
         } else {
             CHK(copy_vec(e, s, p + ".1.g", {D}, &b.norm1_g));
             CHK(copy_vec(e, s, p + ".3.g", {D}, &b.norm2_g));
             if (i >= c.depth / 2 && e->ws.get(p + ".0.weight"))
-                CHK(pack_linear<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
+                CHK(pack_linear_bb<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
         }
     }
     if (dit) {
@@ -172,7 +193,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
     } else {
         CHK(copy_vec(e, s, "norm_out.g", {D}, &P.norm_out_g));
     }
-    CHK(pack_linear<T>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out));
+    CHK(pack_linear_bb<T>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out));
     HIPCHK(hipGetLastError());
     return F5_OK;
 }
@@ -335,7 +356,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(D, e->kin));
-    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
+    HIPCHK(egemm<T>(e, s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
                           EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}, -1, ml, mh));
     pr.end(s);
     const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
@@ -360,15 +381,15 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
                               -1, ml, mh));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
-        HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+        HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
                               EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml, mh));
         pr.end(s);
         pr.begin(PC_LN, s);
@@ -379,10 +400,10 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(F, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml, mh));
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml, mh));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, F));
-        HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
+        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
                               EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh));
         pr.end(s);
     }
@@ -393,7 +414,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(mel, D));
-    HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
+    HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
                           EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml, mh));
     pr.end(s);
     return F5_OK;
@@ -418,7 +439,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gfl(rows_in, D, e->kin));
-    HIPCHK(launch_gemm<T>(s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows_in, D, e->kin_pad,
+    HIPCHK(egemm<T>(e, s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows_in, D, e->kin_pad,
                           EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
     pr.end(s);
     const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
@@ -449,7 +470,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             KCHK();
             pr.end(s);
             pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
-            HIPCHK(launch_gemm<T>(s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
+            HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
                                   EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
             pr.end(s);
         }
@@ -458,14 +479,14 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()}));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
-        HIPCHK(launch_gemm<T>(s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
+        HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
                               EpiGateRes{w.x, w.x, D, bw.out.b, nullptr, 0, Nt, lens_dev}));
         pr.end(s);
         pr.begin(PC_LN, s);
@@ -473,10 +494,10 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, F, D));
-        HIPCHK(launch_gemm<T>(s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, F));
-        HIPCHK(launch_gemm<T>(s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}));
+        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}));
         pr.end(s);
     }
     pr.begin(PC_LN, s);
@@ -484,7 +505,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gfl(rows, mel, D));
-    HIPCHK(launch_gemm<T>(s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}));
+    HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}));
     pr.end(s);
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL(strip_first_token_kernel, dim3(ew_blocks((long)rows_in * mel / 4)), dim3(256), 0, s, w.pred_all, w.pred, Bp, N, mel);

@@ -171,6 +171,7 @@ template <typename T> struct Packed {
 struct f5_engine {
     f5_config cfg{};
     int inner = 0, kin = 0, kin_pad = 0, modN = 0;
+    bool split16 = false;      // F5_PREC_F16X3: the f32 engine with the backbone GEMMs on the f16 pipe (gemm2.h MODE 3)
     WeightStore ws;
     std::vector<void*> owned;  // packed buffers
     Packed<float> pf;

@@ -69,6 +69,33 @@ __device__ __forceinline__ void wait_row(int kk, int i, u32x4 (&af)[2][MI], u32x
 #undef F5_WR
 }
 
+// ---- MODE 3: f32 operands, products on the f16 matrix pipe ("f16x3", F5_PREC_F16X3) -------------------------------------------
+// a = a_hi + a_lo with a_hi = f16(a), a_lo = f16(a - a_hi): 22 significant bits (v_mfma_f32_16x16x32_f16 keeps f16 subnormal
+// inputs -- tools/f16_denorm.py -- so a_lo is good down to 2^-25 absolute);  a w ~= a_hi w_hi + a_lo w_hi + a_hi w_lo, every
+// product exact in the f32 accumulator, the dropped a_lo w_lo term ~2^-22 relative.  Three 16-cycle f16 MFMAs replace eight
+// 32-cycle f32 ones per 32-deep K-tile.
+// The A operand stays f32 in memory and in LDS (same LDS-DMA ring as the f32 kernel) and is split in registers after the
+// fragment read; the W operand is split ONCE (split_planar_kernel, elementwise.h) into the same 128 bytes per 32 elements:
+//   16-byte chunk g (g = 0..3) = f16 hi of k = 4g..4g+3, 16+4g..16+4g+3;   chunk 4 + g = the f16 lo of the same k
+// which is exactly what lane group g of the f32 fragment reads (chunk g, chunk 4 + g) returns for A as 8 floats -- so both
+// operands feed slot s of lane group g with the same k and the swizzled image, the DMA and the read addresses are unchanged.
+// |a| must stay below 65504 (as in the f16 precision).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ void split8_f16(const u32x4& c0, const u32x4& c1, f16x8& hi, f16x8& lo) {
+    const f32x4 x0 = __builtin_bit_cast(f32x4, c0), x1 = __builtin_bit_cast(f32x4, c1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t v = p < 2 ? f32x2_t{x0[2 * p], x0[2 * p + 1]} : f32x2_t{x1[2 * p - 4], x1[2 * p - 3]};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+        const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+        const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+        hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+        lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+    }
+}
+template <int N> __device__ __forceinline__ void tie(u32x4& a) { asm volatile("" : "+v"(a)); }
+
 // Implicit-GEMM Conv1d over a time-major [rows, C] activation (BigVGAN's dilated convolutions, bigvgan.hip): K index
 // tap * C + ci of the tap-major weight operand multiplies A[row + (tap - half) * dil][ci], so K-tile kt of the A operand
 // starts (kt / tpt - half) * dil ROWS away and at column (kt % tpt) * KT -- no im2col operand is materialised.  The caller
@@ -270,6 +297,34 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
                 for (int j = 0; j < NJ; ++j) lds_read_b128_asm(wf[kk][j], sbu + w_row_off + j * 16 * GEMM_ROW_BYTES + co);
 #pragma unroll
                 for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
+            }
+            if constexpr (MODE == 3) {
+                // row i needs both halves of a[i] and (i == 0) every w fragment: the last of them is read (MI + NJ) + NJ + i
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    wait_row<R, MI, NJ>(1, i, af, wf);
+                    tie<0>(af[0][i]);
+                    if (i == 0) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) tie<0>(wf[0][j]);
+                    }
+                    f16x8 ah, al;
+                    split8_f16(af[0][i], af[1][i], ah, al);
+                    // term-major: consecutive MFMAs write different accumulators (a dependent MFMA waits out the whole
+                    // pipeline of its predecessor)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const f16x8 w = __builtin_bit_cast(f16x8, wf[term == 0 ? 1 : 0][j]);   // lo hi hi
+                            const f16x8 a = term == 1 ? al : ah;                                    // hi lo hi
+                            if (j < NJ - NT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a, acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w, acc[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+                return;
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {

@@ -39,7 +39,20 @@ inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
 
 template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                 const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}) {
+                                 const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}, bool split = false) {
+    if constexpr (std::is_same_v<T, float>) {
+        if (split) {   // W in the split_planar layout, products on the f16 pipe (gemm2.h MODE 3)
+            if (cv.tpt != 0) return hipErrorInvalidValue;
+            switch (cfg) {
+                case G3_256x256_PP:
+                case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+            }
+        }
+    } else if (split) return hipErrorInvalidValue;
     switch (cfg) {
         case G3_256x256_PP: if (cv.tpt == 0) return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);   // (no conv mode: falls through)
         case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
@@ -54,15 +67,16 @@ inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W,
 template <typename T, typename Epi>
 inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                               const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0,
-                              const GemmConv& cv = GemmConv{}) {
+                              const GemmConv& cv = GemmConv{}, bool split = false) {
     if (M <= 0 || N <= 0) return hipSuccess;
+    if (split && (K % (GEMM_ROW_BYTES / (int)sizeof(T)) != 0 || force_cfg == -2)) return hipErrorInvalidValue;   // split operands: v2 kernels only
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
     if (cv.tpt > 0 && (K % KT != 0 || force_cfg == -2)) return hipErrorInvalidValue;   // implicit conv: v2 kernels only
     // (m_hint: the row count the caller expects behind m_limit -- the tile is chosen for it, the grid covers M)
     if (K % KT == 0 && force_cfg != -2)
         return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi,
                                       force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi)),
-                                      m_limit, cv);
+                                      m_limit, cv, split);
     if (m_limit) return hipErrorInvalidValue;
     return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }

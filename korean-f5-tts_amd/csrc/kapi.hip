@@ -14,6 +14,14 @@ using namespace f5;
 // precision dispatch of a function template call FN<T>(args...)
 #define F5K_BY_PREC(prec, FN, ...) \
     ((prec) == F5_PREC_BF16 ? FN<bf16_t>(__VA_ARGS__) : (prec) == F5_PREC_F16 ? FN<f16_t>(__VA_ARGS__) : FN<float>(__VA_ARGS__))
+// F5_PREC_F16X3 runs the f32 instantiation with the W operand split (f5k_gemm / f5k_gemm_time only)
+static bool g_split16 = false;
+template <typename T> static hipError_t maybe_split(hipStream_t s, T* w, size_t elems) {
+    if constexpr (std::is_same_v<T, float>) {
+        if (g_split16) hipLaunchKernelGGL(split_planar_kernel, dim3(ew_blocks((long)(elems / 32))), dim3(256), 0, s, w, (long)(elems / 32));
+    }
+    return hipGetLastError();
+}
 
 template <typename T>
 static int gemm_impl(const float* A, const float* W, const float* bias, int act, float* out, int M, int N, int K, int tm,
@@ -25,8 +33,11 @@ static int gemm_impl(const float* A, const float* W, const float* bias, int act,
     hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)M * Kp)), dim3(256), 0, s, A, K, M, K, a.p, Kp, M);
     hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(ew_blocks((long)N * Kp)), dim3(256), 0, s, W, K, N, K, w.p, Kp, N);
     KCHK();
+    const bool split = g_split16 && std::is_same_v<T, float>;
+    if (split && tm > 0) return fail(F5_EINVAL, "f5k_gemm: the split-operand mode has no v1 kernel");
+    HIPCHK(maybe_split<T>(s, w.p, (size_t)N * Kp));
     if (tm > 0) HIPCHK(launch_gemm_v1<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm, tn));
-    else HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm < 0 ? -tm : -1));
+    else HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm < 0 ? -tm : -1, nullptr, 0, GemmConv{}, split));
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
 }
@@ -37,7 +48,10 @@ extern "C" int f5k_gemm(int32_t prec, const float* A, const float* W, const floa
     if (tm > 0 && !((tm == 128 && (tn == 128 || tn == 64)) || (tm == 64 && tn == 64))) return fail(F5_EINVAL, "f5k_gemm: bad tile");
     if (tm < 0 && tm != -2 && tm != -8 && tm != -9 && tm != -10 && tm != -13 && tm != -20) return fail(F5_EINVAL, "f5k_gemm: bad v2 / v3 config id");
     hipStream_t s = (hipStream_t)stream;
-    return F5K_BY_PREC(prec, gemm_impl, A, W, bias, act, out, M, N, K, tm, tn, s);
+    g_split16 = prec == F5_PREC_F16X3;
+    const int rc = F5K_BY_PREC(prec, gemm_impl, A, W, bias, act, out, M, N, K, tm, tn, s);
+    g_split16 = false;
+    return rc;
 }
 
 template <typename T>
@@ -66,7 +80,8 @@ static int gemm_time_impl(int M, int N, int K, int tm, int tn, int iters, float*
     HIPCHK(hipEventCreate(&e1));
     auto go = [&]() -> hipError_t {
         if (tm > 0) return launch_gemm_v1<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm, tn);
-        return launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm < 0 ? -tm : -1);
+        return launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<T>{o.p, N, nullptr, 0}, tm < 0 ? -tm : -1, nullptr, 0, GemmConv{},
+                              g_split16 && std::is_same_v<T, float>);
     };
     for (int i = 0; i < 3; ++i) HIPCHK(go());
     HIPCHK(hipEventRecord(e0, s));
@@ -85,7 +100,10 @@ extern "C" int f5k_gemm_time(int32_t prec, int32_t M, int32_t N, int32_t K, int3
                              float* avg_us, f5_stream stream) {
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (N % 4)) return fail(F5_EINVAL, "f5k_gemm_time: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    return F5K_BY_PREC(prec, gemm_time_impl, M, N, K, tm, tn, iters, avg_us, s);
+    g_split16 = prec == F5_PREC_F16X3;   // (timing only: the random W bits are used as they are)
+    const int rc = F5K_BY_PREC(prec, gemm_time_impl, M, N, K, tm, tn, iters, avg_us, s);
+    g_split16 = false;
+    return rc;
 }
 
 // packs fp32 [Bp,H,N,64] q/k/v into the engine layouts (q scaled, v transposed) -- test-side glue only
@@ -126,7 +144,7 @@ static int attn_impl(const float* q, const float* k, const float* v, const int32
     hipLaunchKernelGGL((pack_qkv_test_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, q, k, v, qd.p, kd.p, vd.p, rows,
                        N, Npad, attention_q_scale<T>());
     KCHK();
-    HIPCHK(launch_attention_any(s, qd.p, kd.p, vd.p, od.p, Bp, H, N, Npad, lens_host ? ld.p : nullptr, Bp));
+    HIPCHK(launch_attention_any(s, qd.p, kd.p, vd.p, od.p, Bp, H, N, Npad, lens_host ? ld.p : nullptr, Bp, nullptr, nullptr, g_split16));
     hipLaunchKernelGGL((to_f32_kernel<T>), dim3(ew_blocks(rows * 64)), dim3(256), 0, s, od.p, out, rows * 64);
     KCHK();
     HIPCHK(hipStreamSynchronize(s));
@@ -137,7 +155,10 @@ extern "C" int f5k_attention(int32_t prec, const float* q, const float* k, const
                              float* out, int32_t Bp, int32_t H, int32_t N, f5_stream stream) {
     if (!q || !k || !v || !out || Bp <= 0 || H <= 0 || N <= 0) return fail(F5_EINVAL, "f5k_attention: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    return F5K_BY_PREC(prec, attn_impl, q, k, v, kv_lens_host, out, Bp, H, N, s);
+    g_split16 = prec == F5_PREC_F16X3;
+    const int rc = F5K_BY_PREC(prec, attn_impl, q, k, v, kv_lens_host, out, Bp, H, N, s);
+    g_split16 = false;
+    return rc;
 }
 
 template <typename T>

@@ -52,8 +52,9 @@ def _ragged_inputs(durs, seed):
 
 
 def test_c2_size_every_precision_vs_oracle():
-    """The benchmarked workload itself (bench.py C2).  f32 must meet the 1e-3 parity bar against the CPU oracle; the
-    bf16 / f16 speed precisions are measured against the same oracle trajectory, printed and gated at ~2x."""
+    """The benchmarked workload itself (bench.py C2).  f32 and f16x3 (f32 data flow, split-f16 GEMM products) must meet the 1e-3
+    parity bar against the CPU oracle; the bf16 / f16 speed precisions are measured against the same oracle trajectory,
+    printed and gated at ~2x."""
     _threads()
     arch = P.config.F5TTS_BASE
     sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
@@ -66,13 +67,13 @@ def test_c2_size_every_precision_vs_oracle():
         o_out, o_traj = O.sample(sd, arch, cond, text, 1024, **kw)
     t_or = time.time() - t0
     errs = {}
-    for prec in ("f32", "f16", "bf16"):
+    for prec in ("f32", "f16x3", "f16", "bf16"):
         out, traj = _model(P.DiT, arch, sd, prec).sample(cond, text, 1024, **kw)
         errs[prec] = ((traj.cpu() - o_traj).abs().max().item(), (out.cpu() - o_out)[:, 256:].abs().max().item())
     print(f"[C2 size, N=1024 NFE=16] oracle {t_or:.0f} s; traj / generated-mel Linf vs oracle: " +
           ", ".join(f"{p} {e[0]:.3e} / {e[1]:.3e}" for p, e in errs.items()) +
           f" (state magnitude {o_traj.abs().max().item():.2f})")
-    assert errs["f32"][0] < TOL_PARITY
+    assert errs["f32"][0] < TOL_PARITY and errs["f16x3"][0] < TOL_PARITY
     for prec in ("f16", "bf16"):
         assert errs[prec][0] < TOL_C2[prec]
 
@@ -101,11 +102,11 @@ def test_c3_chunked_base_batch_vs_oracle():
     assert e_all < TOL_PARITY
     for i, (d, r) in enumerate(zip(durs, refs)):
         assert torch.equal(out[i, :r].cpu(), cond[i, :r]), "prompt frames are returned verbatim (cfm.py:221-223)"
-    for prec in ("f16", "bf16"):
+    for prec in ("f16x3", "f16", "bf16"):
         o16, t16 = _model(P.DiT, arch, sd, prec).sample(cond, text, torch.tensor(durs), **kw)
         e16 = (t16.cpu() - o_traj).abs().max().item()
         print(f"[C3 chunked] {prec} traj Linf {e16:.3e}")
-        assert e16 < TOL_C2[prec]
+        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C2[prec])
 
 
 def test_c3_full_job_properties(monkeypatch):
@@ -184,8 +185,8 @@ def test_c5_base_unett_batch_vs_oracle():
     e = (traj.cpu() - o_traj).abs().max().item()
     print(f"[C5 UNetT Base, B=8 N=1024, 1 step] oracle {t_or:.0f} s; f32 traj Linf {e:.3e}")
     assert e < TOL_PARITY
-    for prec in ("f16", "bf16"):
+    for prec in ("f16x3", "f16", "bf16"):
         o16, t16 = _model(P.UNetT, arch, sd, prec).sample(cond, text, N, **kw)
         e16 = (t16.cpu() - o_traj).abs().max().item()
         print(f"[C5 UNetT Base] {prec} traj Linf {e16:.3e}")
-        assert e16 < TOL_C2[prec]
+        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C2[prec])

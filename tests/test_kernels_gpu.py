@@ -20,8 +20,8 @@ TDTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}
 
 
 def rnd(prec, x):
-    """x as the kernel's MFMA operand type sees it (f32: unchanged)."""
-    return x if prec == "f32" else x.to(TDTYPE[prec]).float()
+    """x as the kernel's MFMA operand type sees it (f32: unchanged; f16x3: hi + lo f16 halves = 22 bits, treated as unchanged)."""
+    return x if prec in ("f32", "f16x3") else x.to(TDTYPE[prec]).float()
 
 
 GEMM_SHAPES = [(2048, 1024, 1024), (2048, 3072, 1024), (2048, 1024, 2048), (300, 100, 1024), (77, 64, 712),
@@ -29,7 +29,7 @@ GEMM_SHAPES = [(2048, 1024, 1024), (2048, 3072, 1024), (2048, 1024, 2048), (300,
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("bf16", 1.5e-2), ("f16", 2e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("bf16", 1.5e-2), ("f16", 2e-3)])
 def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).to(DEV)
@@ -78,7 +78,7 @@ def sdpa_ref(q, k, v, lens=None):
 
 # tol: against SDPA of the unrounded operands; tol_r: against SDPA of the operands as the kernel rounds them (what is
 # left is the 16-bit rounding of P inside the kernel and f32 accumulation)
-ATTN_TOLS = [("f32", 3e-5, 3e-5), ("bf16", 2e-2, 6e-3), ("f16", 3e-3, 8e-4)]
+ATTN_TOLS = [("f32", 3e-5, 3e-5), ("f16x3", 3e-5, 3e-5), ("bf16", 2e-2, 6e-3), ("f16", 3e-3, 8e-4)]
 
 
 @pytest.mark.parametrize("Bp,H,N", [(2, 16, 1024), (1, 4, 64), (2, 4, 48), (3, 2, 200), (1, 2, 129), (2, 3, 777)])
@@ -95,7 +95,7 @@ def test_attention_matches_sdpa(Bp, H, N, prec, tol, tol_r):
     assert e_r < tol_r
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2e-2), ("f16", 3e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f16x3", 3e-5), ("bf16", 2e-2), ("f16", 3e-3)])
 def test_attention_key_padding_mask_and_peaked_softmax(prec, tol):
     """attn_mask_enabled path (modules.py:501-506) + a forced running-max jump (one key dominates late)."""
     g = torch.Generator().manual_seed(3)
@@ -118,7 +118,7 @@ def _as_operands(prec, q, k, v):
     return rnd(prec, q * qs) / qs, rnd(prec, k), rnd(prec, v)
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("bf16", 2.5e-2), ("f16", 4e-3)])
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-5), ("f16x3", 1e-4), ("bf16", 2.5e-2), ("f16", 4e-3)])
 def test_attention_reference_tracking_extremes(prec, tol):
     """The 16-bit kernel keeps a lazily updated softmax reference (attn2.h): scores that keep growing tile after tile
     (reference moves many times), scores that are all very negative (the first-tile reference must follow DOWN or the

@@ -59,11 +59,12 @@ def valid_frames(meta, a):
     return (torch.arange(N)[None, :] < d[:, None])[..., None]
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])     # the two precisions held to the 1e-3 parity bar (f16x3: split-f16 products)
 @pytest.mark.parametrize("name", CASES)
-def test_sample_parity_f32_vs_reference_vectors(name):
+def test_sample_parity_f32_vs_reference_vectors(name, prec):
     meta, a = load_golden(name)
     sd = synthetic_weights(meta)
-    model = build_cfm(meta, sd, "f32")
+    model = build_cfm(meta, sd, prec)
     out, traj = run_case(meta, a, model)
     assert out.shape == a["out"].shape and traj.shape == a["traj"].shape
     packed = bool(meta["arch"].get("attn_mask_enabled")) and traj.shape[1] > 1
@@ -73,7 +74,7 @@ def test_sample_parity_f32_vs_reference_vectors(name):
     v = valid_frames(meta, a) if packed else torch.ones_like(a["traj"][0, :, :, :1], dtype=torch.bool)
     e_out = ((out.cpu() - a["out"]) * v).abs().max().item()
     e_traj = ((traj.cpu() - a["traj"]) * v).abs().max().item()
-    print(f"[parity f32] {name}: out Linf {e_out:.3e} traj Linf {e_traj:.3e}" + (" (valid frames; packed rows)" if packed else ""))
+    print(f"[parity {prec}] {name}: out Linf {e_out:.3e} traj Linf {e_traj:.3e}" + (" (valid frames; packed rows)" if packed else ""))
     assert e_traj < TOL_PARITY and e_out < TOL_PARITY
     if packed:
         pad = ~v.expand_as(traj[0].cpu())
