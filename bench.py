@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--attn-mask", action="store_true", help="c3: run with attn_mask_enabled=True (padded keys masked)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--vocoder-precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="c5: BigVGAN GEMM precision (f16x3 = split-f16 products, f32-level results)")
     ap.add_argument("--no-precisions", action="store_true", help="skip the per-precision record")
     ap.add_argument("--no-c4", action="store_true", help="skip the 256-utterance data-parallel job")
     ap.add_argument("--c4-utts", type=int, default=256)
@@ -204,7 +206,7 @@ def main():
 
     tr, model = build_model(args.precision)
     if args.workload == "c5":   # BASELINE config 5: E2-TTS + BigVGAN (the reference calls it as vocoder(mel), utils_infer.py:705)
-        _bv = P.BigVGAN(P.config.BIGVGAN_V2_24K).init_synthetic(seed=1).to(dev)
+        _bv = P.BigVGAN(P.config.BIGVGAN_V2_24K, precision=args.vocoder_precision).init_synthetic(seed=1).to(dev)
         voc = type("BigVGANDecode", (), {"decode": staticmethod(lambda mel: _bv(mel)), "state_dict": _bv.state_dict})()
     else:
         voc = P.Vocos(P.config.VOCOS_24K).init_synthetic(seed=1).to(dev)
@@ -282,7 +284,7 @@ def main():
                                 "c3": "C3: F5-TTS Base, %d variable-length utterances/rank/step padded to %d frames (prompt = len/4), "
                                       "NFE=%d, cfg 2.0, sway -1, attn_mask_enabled=%s, per-item Vocos decode" % (B, N, args.nfe, bool(args.attn_mask)),
                                 "c5": "C5: E2-TTS UNetT Base, %d utterances/rank/step, prompt %d + generated %d frames, NFE=%d, cfg 2.0, "
-                                      "sway -1, BigVGAN v2 decode (24 kHz, 100 band, 256x; parity unpinned)" % (B, ref, gen, args.nfe)}[args.workload],
+                                      "sway -1, BigVGAN v2 decode (24 kHz, 100 band, 256x; %s; parity unpinned)" % (B, ref, gen, args.nfe, args.vocoder_precision)}[args.workload],
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }

@@ -156,7 +156,8 @@ typedef struct f5_bigvgan_config {
     int32_t resblock_dilations[4];    /* ... with dilations 1, 3, 5 on the first conv of each pair */
     int32_t use_tanh_at_final;        /* 0: clamp(-1, 1) */
     int32_t use_bias_at_final;        /* 0 */
-    int32_t reserved[4];
+    int32_t precision;                /* F5_PREC_F32 (0) or F5_PREC_F16X3: the wide stages' convolutions as split-f16 products */
+    int32_t reserved[3];
 } f5_bigvgan_config;
 int f5_bigvgan_create(const f5_bigvgan_config* cfg, f5_bigvgan** out);
 int f5_bigvgan_destroy(f5_bigvgan* v);

@@ -31,7 +31,8 @@ class f5_bigvgan_config(C.Structure):
     _fields_ = [("num_mels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("num_upsamples", C.c_int32),
                 ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("num_kernels", C.c_int32),
                 ("resblock_kernel_sizes", C.c_int32 * 4), ("num_dilations", C.c_int32), ("resblock_dilations", C.c_int32 * 4),
-                ("use_tanh_at_final", C.c_int32), ("use_bias_at_final", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("use_tanh_at_final", C.c_int32), ("use_bias_at_final", C.c_int32), ("precision", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class f5_vocos_config(C.Structure):

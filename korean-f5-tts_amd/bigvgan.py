@@ -30,8 +30,13 @@ def kaiser_sinc_filter1d(cutoff: float, half_width: float, kernel_size: int) -> 
 
 
 class BigVGAN(nn.Module):
-    def __init__(self, cfg: dict = BIGVGAN_V2_24K, device=None):
+    def __init__(self, cfg: dict = BIGVGAN_V2_24K, device=None, precision: str = "f32"):
+        """precision: "f32" (f32 MFMA throughout) or "f16x3" (the wide stages' convolutions as split-f16 products, include/f5_hip.h
+        F5_PREC_F16X3: f32-level results, ~2.5x the f32 GEMM rate)."""
         super().__init__()
+        if precision not in ("f32", "f16x3"):
+            raise ValueError("BigVGAN precision must be 'f32' or 'f16x3'")
+        self.precision = precision
         self.cfg = dict(cfg)
         self._sd: dict[str, torch.Tensor] = {}
         self._h = None
@@ -109,6 +114,7 @@ class BigVGAN(nn.Module):
         for m, d in enumerate(c["resblock_dilation_sizes"]):
             cfg.resblock_dilations[m] = d
         cfg.use_tanh_at_final, cfg.use_bias_at_final = int(bool(c.get("use_tanh_at_final"))), int(bool(c.get("use_bias_at_final")))
+        cfg.precision = _lib.PRECISIONS[self.precision]
         h = C.c_void_p()
         with torch.cuda.device(dev):
             _lib.check(lib.f5_bigvgan_create(C.byref(cfg), C.byref(h)), "f5_bigvgan_create")

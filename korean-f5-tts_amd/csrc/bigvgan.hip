@@ -328,10 +328,10 @@ struct BT {
     float* p = nullptr;
     std::vector<int64_t> shape;
 };
-struct BConv { float *w = nullptr, *b = nullptr, *wn = nullptr; int ld = 0; };   // wn: bv_pack_narrow_kernel layout (C < 64 only)          // [Co, ld] tap-major, ld = round_up(k C, 32)
+struct BConv { float *w = nullptr, *b = nullptr, *wn = nullptr; int ld = 0; bool split = false; };   // split: w in the split_planar layout (F5_PREC_F16X3)   // wn: bv_pack_narrow_kernel layout (C < 64 only)          // [Co, ld] tap-major, ld = round_up(k C, 32)
 struct BAct { float *alpha = nullptr, *beta = nullptr; };
 struct BRes { std::vector<BConv> c1, c2; std::vector<BAct> act; int k = 0; };
-struct BUp { float *w = nullptr, *b = nullptr; int ci = 0, co = 0, k = 0, u = 0, ld = 0; };
+struct BUp { float *w = nullptr, *b = nullptr; int ci = 0, co = 0, k = 0, u = 0, ld = 0; bool split = false; };
 }  // namespace
 
 struct f5_bigvgan {
@@ -364,6 +364,8 @@ extern "C" int f5_bigvgan_create(const f5_bigvgan_config* c, f5_bigvgan** out) {
             return fail(F5_EINVAL, "f5_bigvgan_create: upsample kernel must be a multiple of its rate and k - u even");
     for (int j = 0; j < c->num_kernels; ++j)
         if (c->resblock_kernel_sizes[j] % 2 == 0) return fail(F5_EINVAL, "f5_bigvgan_create: resblock kernels must be odd");
+    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_F16X3)
+        return fail(F5_EINVAL, "f5_bigvgan_create: precision must be F5_PREC_F32 or F5_PREC_F16X3");
     f5_bigvgan* v = new f5_bigvgan();
     v->cfg = *c;
     v->kpre = round_up(7 * c->num_mels, 32);
@@ -438,6 +440,11 @@ static int bconv(f5_bigvgan* v, hipStream_t s, const std::string& pfx, int Co, i
         hipLaunchKernelGGL(bv_pack_narrow_kernel, dim3(ew_blocks((long)(K / 4) * NT * 64)), dim3(256), 0, s, c->w, c->wn, Co, c->ld, K, NT);
         KCHK();
     }
+    c->split = v->cfg.precision == F5_PREC_F16X3 && !c->wn;     // (the narrow stages keep f32 MFMA: 7 % of the generator's flops)
+    if (c->split) {
+        hipLaunchKernelGGL(split_planar_kernel, dim3(ew_blocks((long)Co * c->ld / 32)), dim3(256), 0, s, c->w, (long)Co * c->ld / 32);
+        KCHK();
+    }
     return F5_OK;
 }
 
@@ -465,6 +472,11 @@ extern "C" int f5_bigvgan_finalize(f5_bigvgan* v, f5_stream stream) {
         CHK(balloc(v, (size_t)u.k * u.co * u.ld, &u.w));
         hipLaunchKernelGGL(bv_pack_convT_kernel, dim3(ew_blocks((long)u.k * u.co * u.ld)), dim3(256), 0, s, t->p, u.w, u.ci, u.co, u.k, u.ld);
         KCHK();
+        u.split = c.precision == F5_PREC_F16X3 && u.ci % 32 == 0;      // (K = ci must be whole K-tiles for the LDS-DMA kernels)
+        if (u.split) {
+            hipLaunchKernelGGL(split_planar_kernel, dim3(ew_blocks((long)u.k * u.co * u.ld / 32)), dim3(256), 0, s, u.w, (long)u.k * u.co * u.ld / 32);
+            KCHK();
+        }
         CHK(bcopy(v, s, p + ".bias", {u.co}, &u.b));
         ch /= 2;
         for (int j = 0; j < c.num_kernels; ++j) {
@@ -564,11 +576,13 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
         hipLaunchKernelGGL(im2col7_kernel, dim3(ew_blocks((long)T * v->kpre)), dim3(256), 0, s, mel + (size_t)b * sb, 0L, (long)sc, (long)st,
                            col, 1, c.num_mels, T, v->kpre);
         KCHK();
-        HIPCHK(launch_gemm<float>(s, col, v->kpre, v->pre.w, v->pre.ld, T, ch, v->kpre, EpiStore<float>{x, ch, v->pre.b, F5_ACT_NONE}));
+        HIPCHK(launch_gemm<float>(s, col, v->kpre, v->pre.w, v->pre.ld, T, ch, v->kpre, EpiStore<float>{x, ch, v->pre.b, F5_ACT_NONE}, -1, nullptr, 0,
+                                  GemmConv{}, v->pre.split));
         for (int i = 0; i < c.num_upsamples; ++i) {
             const BUp& u = v->ups[i];
             // ConvTranspose1d: Z[L, k Co] = x[L, Ci] W'^T, then gather
-            HIPCHK(launch_gemm<float>(s, x, u.ci, u.w, u.ld, (int)L, u.k * u.co, u.ci, EpiStore<float>{Z, u.k * u.co, nullptr, F5_ACT_NONE}));
+            HIPCHK(launch_gemm<float>(s, x, u.ci, u.w, u.ld, (int)L, u.k * u.co, u.ci, EpiStore<float>{Z, u.k * u.co, nullptr, F5_ACT_NONE}, -1, nullptr, 0,
+                                      GemmConv{}, u.split));
             hipLaunchKernelGGL(bv_upsample_gather_kernel, dim3(ew_blocks(L * u.u * (u.co / 4))), dim3(256), 0, s, Z, u.b, x, L, u.co, u.k, u.u,
                                (u.k - u.u) / 2);
             KCHK();
@@ -586,9 +600,9 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
                 if (narrow_ok && cw.wn && conv_narrow_ok(ch, k, d))
                     return launch_conv_narrow(s, acti, cw.wn, cw.b, epi_res(epi), epi_out(epi), L, ch, k, d);
                 if (implicit) return launch_gemm<float>(s, acti, ch, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0,
-                                                        GemmConv{ch / 32, d, (k - 1) / 2});
+                                                        GemmConv{ch / 32, d, (k - 1) / 2}, cw.split);
                 hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (cw.ld / 4))), dim3(256), 0, s, acti, col, L, ch, k, d, cw.ld);
-                return launch_gemm<float>(s, col, cw.ld, cw.w, cw.ld, (int)L, ch, cw.ld, epi);
+                return launch_gemm<float>(s, col, cw.ld, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0, GemmConv{}, cw.split);
             };
             for (int j = 0; j < c.num_kernels; ++j) {
                 const BRes& rb = v->res[(size_t)i * c.num_kernels + j];

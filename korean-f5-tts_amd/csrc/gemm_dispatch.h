@@ -42,14 +42,13 @@ inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W,
                                  const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}, bool split = false) {
     if constexpr (std::is_same_v<T, float>) {
         if (split) {   // W in the split_planar layout, products on the f16 pipe (gemm2.h MODE 3)
-            if (cv.tpt != 0) return hipErrorInvalidValue;
             switch (cfg) {
                 case G3_256x256_PP:
-                case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
-                case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
-                case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
-                case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
-                default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
             }
         }
     } else if (split) return hipErrorInvalidValue;

@@ -52,19 +52,20 @@ def test_slaney_filterbank_and_bigvgan_mel_shape():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("cfg_name,T,B", [("BIGVGAN_TINY", 37, 2), ("BIGVGAN_TINY", 5, 1), ("BIGVGAN_MID", 24, 1)])
-def test_bigvgan_hip_vs_oracle(cfg_name, T, B):
+def test_bigvgan_hip_vs_oracle(cfg_name, T, B, prec):
     cfg = getattr(P.config, cfg_name, None) or dict(P.config.BIGVGAN_V2_24K, upsample_initial_channel=256)   # MID: all 6 stages, 256 -> 4 channels
     V = P.weights.synthetic_state_dict(P.weights.bigvgan_param_shapes(cfg), seed=3)
     mel = torch.randn(B, T, 100, generator=torch.Generator().manual_seed(T)).permute(0, 2, 1)   # the callers' transposed view
     ref = BO.bigvgan_forward(V, cfg, mel)
-    voc = P.BigVGAN(cfg)
+    voc = P.BigVGAN(cfg, precision=prec)
     voc.load_state_dict(V)
     voc.to("cuda:0")
     wav = voc(mel.to("cuda:0")).cpu()
     assert wav.shape == ref.shape
     e = (wav - ref).abs().max().item()
-    print(f"[bigvgan f32] {cfg_name} T={T}: wav Linf {e:.3e} (peak {ref.abs().max().item():.3f}, clipped {(ref.abs() >= 1).float().mean().item():.3f})")
+    print(f"[bigvgan {prec}] {cfg_name} T={T}: wav Linf {e:.3e} (peak {ref.abs().max().item():.3f}, clipped {(ref.abs() >= 1).float().mean().item():.3f})")
     assert e < 2e-4 * max(1.0, ref.abs().max().item())
 
 
