@@ -209,15 +209,34 @@ def cross_fade_concat(waves: list[np.ndarray], cross_fade_duration_: float = cro
 def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
                         progress=None, target_rms=target_rms, cross_fade_duration=cross_fade_duration,
                         nfe_step=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
-                        speed=speed, fix_duration=fix_duration, device=None, seed=None):
-    """Returns (final_wave f32 numpy, sample_rate, combined mel [100, T_total]) like the non-streaming branch."""
+                        speed=speed, fix_duration=fix_duration, device=None, seed=None, text_tokenizer=None):
+    """Returns (final_wave f32 numpy, sample_rate, combined mel [100, T_total]) like the non-streaming branch.
+
+    Text front-end: the reference turns `ref_text + gen_text` into tokens per `model_obj._tokenizer_type` -- for the kor_*
+    types through Korean G2P / jamo decomposition / allophone rules (utils_infer.py:549-660: g2pk and the repo's own rule
+    tables, CPU string work outside this engine's scope).  Here the string is handed to `model_obj.sample`, which maps it
+    per character through `vocab_char_map` (the reference's "custom"/char path); a kor_* model therefore needs
+    `text_tokenizer`: a callable str -> list[str] producing exactly the reference's tokens.  Without one this raises rather
+    than synthesise from ids that are almost all 0 (raw Hangul is not in a jamo / allophone vocabulary)."""
     audio, sr = ref_audio
     device = device if device is not None else model_obj.device
+    tok_type = getattr(model_obj, "_tokenizer_type", "custom")
+    if text_tokenizer is None and isinstance(tok_type, str) and tok_type.startswith("kor_"):
+        raise NotImplementedError(f"model tokenizer type {tok_type!r}: pass text_tokenizer= (str -> list[str], the reference's "
+                                  "utils_infer.py:549-660 conversion) -- the Korean G2P / allophone front-end is not part of this engine")
     waves, specs = [], []
     for gen_text in gen_text_batches:
         a, rms, rtext, ref_len, duration = prompt_numerics(audio, sr, ref_text, gen_text, speed, fix_duration, target_rms)
         a = a.to(device)
-        text_list = [rtext + gen_text]
+        text_list = [text_tokenizer(rtext + gen_text)] if text_tokenizer is not None else [rtext + gen_text]
+        vocab = getattr(model_obj, "vocab_char_map", None)
+        if vocab is not None:
+            toks = text_list[0]
+            missing = sum(1 for c in toks if c not in vocab)
+            if len(toks) >= 8 and missing > 0.3 * len(toks):
+                import warnings
+                warnings.warn(f"{missing} of {len(toks)} text tokens are not in the model's vocabulary (they all map to id 0): "
+                              "this checkpoint expects a tokenised input (text_tokenizer=)", RuntimeWarning, stacklevel=2)
         with torch.inference_mode():
             generated, _ = model_obj.sample(cond=a, text=text_list, duration=duration, steps=nfe_step,
                                             cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, seed=seed)
@@ -234,7 +253,8 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
 
 def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_type=mel_spec_type, target_rms=target_rms,
                   cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
-                  sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, seed=None):
+                  sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, seed=None,
+                  text_tokenizer=None):
     """ref_audio = (tensor [channels, nw], sample_rate) instead of a path (no torchaudio.load here); otherwise
     utils_infer.py:453-498: max_chars from the prompt's bytes-per-second, chunk, infer_batch_process."""
     audio, sr = ref_audio
@@ -243,4 +263,4 @@ def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_ty
     return infer_batch_process((audio, sr), ref_text, batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
                                target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
                                cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed,
-                               fix_duration=fix_duration, device=device, seed=seed)
+                               fix_duration=fix_duration, device=device, seed=seed, text_tokenizer=text_tokenizer)

@@ -113,6 +113,19 @@ def test_infer_batch_process_matches_reference_harness():
         assert np.allclose(wave_r, wave_m, atol=1e-7) and np.array_equal(spec_r, spec_m)
 
 
+def test_korean_tokenizer_types_need_an_explicit_tokenizer():
+    """kor_* checkpoints expect jamo / allophone tokens (utils_infer.py:549-660, out of scope): raw text must not be silently
+    mapped to id 0; a caller-supplied tokenizer is passed through to sample() as list[list[str]]."""
+    audio = torch.randn(1, 24000, generator=torch.Generator().manual_seed(0)) * 0.1
+    m = FakeModel()
+    m._tokenizer_type = "kor_allophone"
+    with pytest.raises(NotImplementedError, match="text_tokenizer"):
+        I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu")
+    I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu",
+                          text_tokenizer=lambda s: ["<" + c + ">" for c in s])
+    assert m.calls and m.calls[0]["text"][0][0] == "<r>" and isinstance(m.calls[0]["text"][0], list)
+
+
 def test_cfm_state_dict_roundtrip_and_load_model_surface(tmp_path):
     """load_checkpoint semantics (utils_infer.py:242-286) on files written here: .pt with ema_model_state_dict,
     .safetensors, PEFT keys; loads need no GPU (weights are uploaded lazily)."""
