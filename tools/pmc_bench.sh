@@ -6,7 +6,7 @@ out=gpurun_out/pmc_bench
 rm -rf $out; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/$n -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 > $out/$n.log 2>&1 || echo "pass $n failed"
+  timeout -k 10 500 rocprofv3 --pmc $c --output-format csv -d $out/$n -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 > $out/$n.log 2>&1 || echo "pass $n failed"
 done
 python - <<'PY'
 import csv, glob, collections
