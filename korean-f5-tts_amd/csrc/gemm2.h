@@ -100,7 +100,9 @@ template <int N> __device__ __forceinline__ void tie(u32x4& a) { asm volatile(""
 // tap * C + ci of the tap-major weight operand multiplies A[row + (tap - half) * dil][ci], so K-tile kt of the A operand
 // starts (kt / tpt - half) * dil ROWS away and at column (kt % tpt) * KT -- no im2col operand is materialised.  The caller
 // pads the activation with half * dil zero rows on both sides.  tpt = K-tiles per tap (C / KT); tpt == 0: plain GEMM.
-struct GemmConv { int tpt = 0, dil = 0, half = 0; };
+// m_base: the epilogue addresses row (m_base + m) for the kernel's row m (a launch over the LAST rows of a larger problem:
+// launch_gemm's remainder launch; the caller passes A already offset by m_base rows).
+struct GemmConv { int tpt = 0, dil = 0, half = 0, m_base = 0; };
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, typename Epi, int MODE = 0>
 __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restrict__ A, int lda, const T* __restrict__ W,
@@ -240,7 +242,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = min(mw + i * 16 + l15, M - 1);
-                rc[i] = epi.row(m);
+                rc[i] = epi.row(m + cv.m_base);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -253,7 +255,7 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = min(mw + i * 16 + g * 4, M - 1);
-                trc[i] = epi.trow(m, M);
+                trc[i] = epi.trow(m + cv.m_base, M + cv.m_base);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) tcc[j] = epi.tcol(min(nw + j * 16 + l15, N - 1));

@@ -72,6 +72,19 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
     if (cv.tpt > 0 && (K % KT != 0 || force_cfg == -2)) return hipErrorInvalidValue;   // implicit conv: v2 kernels only
     // (m_hint: the row count the caller expects behind m_limit -- the tile is chosen for it, the grid covers M)
+    // A many-row problem whose row count is a few rows past a multiple of 256 (UNetT: 16 x 1025 = 16,400 rows) would pay
+    // a whole extra round of 256-row tiles for the last 16 rows: the 256-row multiple goes to the ping-pong kernel and the
+    // remainder to one row of 64x64 tiles (same K order per element: bit-identical to a single launch).
+    if (K % KT == 0 && force_cfg == -1 && !m_limit && cv.tpt == 0 && !split && sizeof(T) == 2 && gemm3_epilogue_ok(epi)) {
+        const int rem = M % 256, main = M - rem;
+        if (rem > 0 && rem <= 64 && main >= 4096 && pick_cfg_v2(main, N, true) == G3_256x256_PP) {
+            hipError_t e = launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, main, N, K, epi, G3_256x256_PP);
+            if (e != hipSuccess) return e;
+            GemmConv tail{};
+            tail.m_base = main;
+            return launch_gemm_v2<T, Epi>(s, A + (size_t)main * lda, lda, W, ldw, rem, N, K, epi, G2_64x64_4W, nullptr, tail);
+        }
+    }
     if (K % KT == 0 && force_cfg != -2)
         return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi,
                                       force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi)),

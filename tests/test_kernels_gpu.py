@@ -44,6 +44,22 @@ def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     assert rel_err(out, ref_r) < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_gemm_many_rows_with_a_small_remainder_is_split_and_bit_identical(prec):
+    """M = 48 x 256 + 16 (UNetT batches: B x 1025 rows): launch_gemm sends the 256-row multiple to the ping-pong kernel and the
+    last 16 rows to 64x64 tiles (gemm_dispatch.h); same K order per element, so equal bit for bit to one forced-tile launch."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 48 * 256 + 16, 1024, 512
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    out = k_gemm(prec, A, W, b)
+    one = k_gemm(prec, A, W, b, tile=(-13, 0))
+    assert torch.equal(out, one)
+    ref = F.linear(rnd(prec, A).double(), rnd(prec, W).double(), b.double()).float()
+    assert rel_err(out, ref) < 2e-5
+
+
 @pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64), (-2, 0), (-8, 0), (-9, 0)])  # v1 tiles, v2 config ids
 @pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_gemm_every_tile_shape_and_identity(tile, prec):
