@@ -17,6 +17,8 @@
 //
 // This file: the C ABI and the precision-independent host logic.  The kernels and the per-call graph of launches are
 // templates over the MFMA operand type (engine_impl.h), instantiated in engine_{bf16,f16,f32}.hip.
+#include <cmath>
+
 #include "engine_types.h"
 
 // precision dispatch of one EngineOps<T> member
@@ -137,6 +139,30 @@ int chunk_utts(f5_engine* e, int B, int N, bool use_cfg, const int32_t* lens_hos
         long total = 0;
         for (int i = 0; i < B; ++i) total += (lens_host[i] + 3) / 4 * 4;
         rows_per_utt = std::max(1L, (long)(use_cfg ? 2 : 1) * total / B);
+    }
+    if (!getenv("F5_CHUNK_ROWS") && (long)B * rows_per_utt > 16384) {
+        // Many rows: the block GEMMs run on 256x256 tiles (gemm3.h), 256 at a time, so their time moves in whole ROUNDS of
+        // tiles: 19,800 rows are 78 row tiles = 312 tiles of the out-projection = two rounds where 1.2 would do.  Choose the
+        // number of equal chunks (8,192 .. 24,576 rows each: large enough for those tiles, small enough for the cache) that
+        // minimises  chunks x sum over the block's GEMMs of (K / 1024) x rounds;  ties go to fewer, larger chunks.
+        // C3 (32 x 2,048 rows): 3 / 4 / 5 chunks cost 42 / 32 / 40 -> 4 x 8 utterances, the measured optimum above.
+        const f5_config& c = e->cfg;
+        const int D = c.dim, inner = e->inner, F = c.ff_dim;
+        const double gn[5] = {3.0 * inner, (double)D, (double)F, (double)D, (double)D};
+        const double gk[5] = {(double)D, (double)inner, (double)D, (double)F, c.backbone == F5_BACKBONE_UNETT ? 1.0 * D : 0.0};   // (skip GEMM: K = 2D on half the layers)
+        const long total = (long)B * rows_per_utt;
+        const long nc_lo = std::max(1L, (total + 24575) / 24576), nc_hi = std::min<long>(B, std::max(nc_lo, total / 8192));
+        double best = 1e300;
+        long best_per = B;
+        for (long nc = nc_lo; nc <= nc_hi; ++nc) {
+            const long per = (B + nc - 1) / nc, chunks = (B + per - 1) / per, rows = per * rows_per_utt;
+            const long rt = rows / 256 + (rows % 256 > 64 ? 1 : 0);      // (a remainder of <= 64 rows runs apart: launch_gemm)
+            double cost = 0;
+            for (int g = 0; g < 5; ++g) cost += gk[g] / 1024.0 * (double)((long)(rt * std::ceil(gn[g] / 256.0) + 255) / 256);
+            cost *= (double)chunks;
+            if (cost < best - 1e-9) { best = cost; best_per = per; }
+        }
+        return (int)best_per;
     }
     long bc = budget / rows_per_utt;
     if (bc < 1) bc = 1;
