@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
                                                        int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
                                                        const int* __restrict__ q_lens, const int* __restrict__ o_row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (q_lens && (int)blockIdx.x * 128 >= q_lens[blockIdx.z % nbatch_lens]) return;   // (block-uniform, before any barrier)
+    // grid: x = (batch row, head), y = query block: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so with
+    // heads on x the query blocks that share one head's K / V meet in ONE XCD's L2 (with query blocks on x every XCD
+    // streamed every head's K / V: tools/probe/attn_probe.hip)
+    if (q_lens && (int)blockIdx.y * 128 >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;   // (block-uniform, before any barrier)
     constexpr int RB = 64 * sizeof(T);          // bytes per 64-element row (128 / 256)
     constexpr int RS = RB + 16;                 // padded LDS row stride
     constexpr int NF = RB / 64;                 // 16-byte fragments per lane per 64-element row (2 / 4)
@@ -42,9 +45,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
     const size_t bh = (size_t)b * H + h;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.y * 128 + wave * 32;
     int kv_len = N;
     if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
     const int nkt = (kv_len + 63) / 64;
@@ -66,8 +69,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = tid + i * 256, row = c / (RB / 16), cc = c % (RB / 16);
-            const int key = kt * 64 + row;
-            rk[i] = key < N ? *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * EPC) : u32x4{0u, 0u, 0u, 0u};
+            // rows past the sequence read the last row (masked below: kv_len <= N).  A conditional load here makes hipcc's
+            // wait-count pass put vmcnt waits BETWEEN the loads of a tile (pessimistic merge at the exec-masked branches):
+            // the wave then sits out a memory round trip per tile before its first MFMA (tools/probe/attn_probe.hip: 12 of 47 us).
+            const int key = min(kt * 64 + row, N - 1);
+            rk[i] = *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * EPC);
             rv[i] = *reinterpret_cast<const u32x4*>(Vt + (bh * 64 + row) * Npad + kt * 64 + cc * EPC);
         }
     };
@@ -216,7 +222,7 @@ inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid((N + 127) / 128, H, Bp);
+    dim3 grid(H * Bp, (N + 127) / 128);
     hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
     return hipGetLastError();
 }
@@ -246,13 +252,15 @@ __device__ __forceinline__ f32x4 mma_h(const u32x4& a, const u32x4& b, f32x4 c) 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int QS>
-static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+// DIAG (tools/attn_probe.hip only; 0 in the product): bit 0 = stage K / V without splitting, 1 = no softmax arithmetic,
+// 2 = no V^T P^T MFMAs, 3 = no K Q^T MFMAs, 4 = no global loads after the first tile -- the cost of each part by omission.
+template <int QS, int NW = 4, int DIAG = 0>
+static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ Vt, float* __restrict__ O, int H, int N,
                                                              int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
                                                              const int* __restrict__ q_lens, const int* __restrict__ o_row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (q_lens && (int)blockIdx.x * (64 * QS) >= q_lens[blockIdx.z % nbatch_lens]) return;
+    if (q_lens && (int)blockIdx.y * (NW * 16 * QS) >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;   // (grid as attn_fwd_kernel)
     constexpr int RS = 128 + 16;                // f16 plane row: 64 elements + pad
     constexpr int PLANE = 64 * RS;
     constexpr int BUF = 4 * PLANE;              // K hi, K lo, V hi, V lo
@@ -260,9 +268,9 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
     const size_t bh = (size_t)b * H + h;
-    const int q0 = blockIdx.x * (64 * QS) + wave * (16 * QS);
+    const int q0 = blockIdx.y * (NW * 16 * QS) + wave * (16 * QS);
     int kv_len = N;
     if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
     const int nkt = (kv_len + 63) / 64;
@@ -288,23 +296,31 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
         }
     }
 
-    // staging: 64 rows x 16 four-float chunks per operand per tile = 4 chunks per thread
-    u32x4 rk[4], rv[4];
+    // staging: 64 rows x 16 four-float chunks per operand per tile = CH chunks per thread
+    constexpr int CH = 1024 / (NW * 64);
+    u32x4 rk[CH], rv[CH];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256, row = c >> 4, cc = c & 15;
-            const int key = kt * 64 + row;
-            rk[i] = key < N ? *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * 4) : u32x4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * (NW * 64), row = c >> 4, cc = c & 15;
+            const int key = min(kt * 64 + row, N - 1);      // (unconditional: see attn_fwd_kernel)
+            rk[i] = *reinterpret_cast<const u32x4*>(K + (bh * N + key) * 64 + cc * 4);
             rv[i] = *reinterpret_cast<const u32x4*>(Vt + (bh * 64 + row) * Npad + kt * 64 + cc * 4);
         }
     };
     auto sstore = [&](int buf) {
         char* base = smem + buf * BUF;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256, row = c >> 4, cc = c & 15;
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * (NW * 64), row = c >> 4, cc = c & 15;
             u32x2 hi, lo;
+            if constexpr (DIAG & 1) {
+                *reinterpret_cast<u32x2*>(base + row * RS + cc * 8) = u32x2{rk[i].x, rk[i].y};
+                *reinterpret_cast<u32x2*>(base + PLANE + row * RS + cc * 8) = u32x2{rk[i].z, rk[i].w};
+                *reinterpret_cast<u32x2*>(base + 2 * PLANE + row * RS + cc * 8) = u32x2{rv[i].x, rv[i].y};
+                *reinterpret_cast<u32x2*>(base + 3 * PLANE + row * RS + cc * 8) = u32x2{rv[i].z, rv[i].w};
+                continue;
+            }
             split4_f16(rk[i], hi, lo);
             *reinterpret_cast<u32x2*>(base + row * RS + cc * 8) = hi;
             *reinterpret_cast<u32x2*>(base + PLANE + row * RS + cc * 8) = lo;
@@ -327,7 +343,7 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
     sstore(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload(kt + 1);
+        if (kt + 1 < nkt && !(DIAG & 16)) gload(kt + 1);
         const char* Ks = smem + (kt & 1) * BUF + l15 * RS + g * 16;
         const char* Vs = smem + (kt & 1) * BUF + 2 * PLANE + l15 * RS;
 
@@ -347,7 +363,7 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
                 kl[ks] = *reinterpret_cast<const u32x4*>(Ks + PLANE + ks * 16 * RS + f * 64);
             }
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < ((DIAG & 8) ? 0 : 3); ++term)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -370,7 +386,7 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
                         if (key_base + ks * 16 + r >= kv_len) s[ks][qs][r] = -1e30f;
         }
 #pragma unroll
-        for (int qs = 0; qs < QS; ++qs) {
+        for (int qs = 0; qs < ((DIAG & 2) ? 0 : QS); ++qs) {
             float mloc = -1e30f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -420,7 +436,7 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
                 vl[dt] = u32x4{b0.x, b0.y, b1.x, b1.y};
             }
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < ((DIAG & 4) ? 0 : 3); ++term)
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -452,28 +468,19 @@ static __global__ __launch_bounds__(256) void attn_split_fwd_kernel(const float*
 inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
                                          int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
                                          const int* o_row_start = nullptr) {
+    // 128 query rows per workgroup as 8 waves x 16 rows: two waves per SIMD (one's softmax / split arithmetic overlaps the other's
+    // MFMAs) sharing one staged K / V tile.  (4 waves x 32 rows: one wave per SIMD, every phase serial: 42 us at C2 against 3x us;
+    // 4 waves x 16 rows: twice the staging per query, 47 us -- tools/probe/attn_probe.hip)
     constexpr int smem = 2 * 4 * 64 * (128 + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<1, 8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // 128-query blocks (32 per wave) when they alone fill the chip twice over; else 64-query blocks: twice the workgroups, so that
-    // a SIMD has a second wave to overlap the softmax / split arithmetic of one with the MFMAs of the other
-    static const int forced = getenv("F5_ATTN_SPLIT_QS") ? atoi(getenv("F5_ATTN_SPLIT_QS")) : 0;
-    const long blocks128 = (long)((N + 127) / 128) * H * Bp;
-    const int qs = forced ? forced : (blocks128 >= 512 ? 2 : 1);
-    if (qs == 2) {
-        dim3 grid((N + 127) / 128, H, Bp);
-        hipLaunchKernelGGL(attn_split_fwd_kernel<2>, grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
-    } else {
-        dim3 grid((N + 63) / 64, H, Bp);
-        hipLaunchKernelGGL(attn_split_fwd_kernel<1>, grid, dim3(256), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
-    }
+    dim3 grid(H * Bp, (N + 127) / 128);
+    hipLaunchKernelGGL((attn_split_fwd_kernel<1, 8>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
     return hipGetLastError();
 }
 
