@@ -237,17 +237,6 @@ inline hipError_t launch_attention(hipStream_t s, const T* Q, const T* K, const 
 //       (the four planes of a tile take the bytes of the two f32 images they replace);
 //   P   (the softmax numerators, f32 accumulators) split in registers into the B operand of V^T P^T.
 // 6 + 6 sixteen-cycle MFMAs per (16 keys x 16 queries x 64) instead of 16 + 16 thirty-two-cycle f32 ones.
-__device__ __forceinline__ void split4_f16(const u32x4& c, u32x2& hi, u32x2& lo) {
-    typedef __attribute__((ext_vector_type(2))) float v2f;
-    typedef __attribute__((ext_vector_type(2))) _Float16 v2h;
-    const f32x4 x = __builtin_bit_cast(f32x4, c);
-    const v2f a{x[0], x[1]}, b{x[2], x[3]};
-    const v2h ah = __builtin_convertvector(a, v2h), bh = __builtin_convertvector(b, v2h);
-    const v2h al = __builtin_convertvector(a - __builtin_convertvector(ah, v2f), v2h);
-    const v2h bl = __builtin_convertvector(b - __builtin_convertvector(bh, v2f), v2h);
-    hi = u32x2{__builtin_bit_cast(unsigned, ah), __builtin_bit_cast(unsigned, bh)};
-    lo = u32x2{__builtin_bit_cast(unsigned, al), __builtin_bit_cast(unsigned, bl)};
-}
 __device__ __forceinline__ f32x4 mma_h(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -258,7 +247,8 @@ template <int QS, int NW = 4, int DIAG = 0>
 static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ Vt, float* __restrict__ O, int H, int N,
                                                              int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
-                                                             const int* __restrict__ q_lens, const int* __restrict__ o_row_start) {
+                                                             const int* __restrict__ q_lens, const int* __restrict__ o_row_start,
+                                                             int o_planar) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (q_lens && (int)blockIdx.y * (NW * 16 * QS) >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;   // (grid as attn_fwd_kernel)
     constexpr int RS = 128 + 16;                // f16 plane row: 64 elements + pad
@@ -457,17 +447,19 @@ static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const fl
         const int q = q0 + qs * 16 + l15;
         const size_t orow = o_row_start ? (size_t)o_row_start[b] + q : (size_t)b * N + q;
         if (q < (o_row_start ? min(N, o_row_start[b + 1] - o_row_start[b]) : N)) {
-            float* dst = O + orow * (H * 64) + h * 64 + g * 4;
+            // (o_planar: the out-projection reads this buffer as a pre-split A operand, f5_common.h store4_planar)
+            float* dst = O + orow * (H * 64);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                store4(dst + dt * 16, o[dt][qs][0] * inv, o[dt][qs][1] * inv, o[dt][qs][2] * inv, o[dt][qs][3] * inv);
+                store4_at(dst, h * 64 + g * 4 + dt * 16, o_planar, o[dt][qs][0] * inv, o[dt][qs][1] * inv, o[dt][qs][2] * inv,
+                          o[dt][qs][3] * inv);
         }
     }
 }
 
 inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
                                          int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
-                                         const int* o_row_start = nullptr) {
+                                         const int* o_row_start = nullptr, int o_planar = 0) {
     // 128 query rows per workgroup as 8 waves x 16 rows: two waves per SIMD (one's softmax / split arithmetic overlaps the other's
     // MFMAs) sharing one staged K / V tile.  (4 waves x 32 rows: one wave per SIMD, every phase serial: 42 us at C2 against 3x us;
     // 4 waves x 16 rows: twice the staging per query, 47 us -- tools/probe/attn_probe.hip)
@@ -480,7 +472,7 @@ inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const fl
         attr_set = true;
     }
     dim3 grid(H * Bp, (N + 127) / 128);
-    hipLaunchKernelGGL((attn_split_fwd_kernel<1, 8>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start);
+    hipLaunchKernelGGL((attn_split_fwd_kernel<1, 8>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
     return hipGetLastError();
 }
 

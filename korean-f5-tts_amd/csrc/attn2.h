@@ -407,18 +407,18 @@ inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, con
 //  batch row b as lens[b % nbl] and may be null)
 inline hipError_t launch_attention_any(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp,
                                        int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool /*split16*/ = false) {
+                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false) {
     return launch_attention_v2<bf16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const f16_t* Q, const f16_t* K, const f16_t* Vt, f16_t* O, int Bp,
                                        int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool /*split16*/ = false) {
+                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false) {
     return launch_attention_v2<f16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H,
                                        int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool split16 = false) {
-    if (split16) return launch_attention_split(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);   // F5_PREC_F16X3
+                                       const int* o_row_start = nullptr, bool split16 = false, bool o_planar = false) {
+    if (split16) return launch_attention_split(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start, o_planar);   // F5_PREC_F16X3
     return launch_attention<float>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 

@@ -96,7 +96,8 @@ __device__ __forceinline__ float4 bv_up_generic(const float* __restrict__ x, lon
 
 static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restrict__ x, float* __restrict__ y, long L, int C,
                                                              const float* __restrict__ log_alpha, const float* __restrict__ log_beta,
-                                                             const float* __restrict__ fu, const float* __restrict__ fd) {
+                                                             const float* __restrict__ fu, const float* __restrict__ fd, int planar) {
+    // planar: rows written pre-split for the split-operand convolution GEMM that reads them (f5_common.h store4_planar)
     __shared__ float sfu[12], sfd[12];
     if (threadIdx.x < 12) { sfu[threadIdx.x] = fu[threadIdx.x]; sfd[threadIdx.x] = fd[threadIdx.x]; }
     __syncthreads();
@@ -141,7 +142,7 @@ static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restr
                     const float g = sfd[m];
                     acc.x += g * a[m].x; acc.y += g * a[m].y; acc.z += g * a[m].z; acc.w += g * a[m].w;
                 }
-                *reinterpret_cast<float4*>(y + t * C + c) = acc;
+                store4_at(y + t * C, c, planar, acc.x, acc.y, acc.z, acc.w);
 #pragma unroll
                 for (int m = 0; m < 10; ++m) a[m] = a[m + 2];
 #pragma unroll
@@ -599,8 +600,9 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             auto conv = [&](const BConv& cw, int k, int d, const auto& epi) -> hipError_t {
                 if (narrow_ok && cw.wn && conv_narrow_ok(ch, k, d))
                     return launch_conv_narrow(s, acti, cw.wn, cw.b, epi_res(epi), epi_out(epi), L, ch, k, d);
+                // (split 2: the activation kernel wrote these rows pre-split -- planar1 / planar2 below)
                 if (implicit) return launch_gemm<float>(s, acti, ch, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0,
-                                                        GemmConv{ch / 32, d, (k - 1) / 2}, cw.split);
+                                                        GemmConv{ch / 32, d, (k - 1) / 2}, cw.split ? 2 : 0);
                 hipLaunchKernelGGL(bv_im2col_kernel, dim3(ew_blocks(L * (cw.ld / 4))), dim3(256), 0, s, acti, col, L, ch, k, d, cw.ld);
                 return launch_gemm<float>(s, col, cw.ld, cw.w, cw.ld, (int)L, ch, cw.ld, epi, -1, nullptr, 0, GemmConv{}, cw.split);
             };
@@ -610,12 +612,15 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
                 HIPCHK(hipMemcpyAsync(rj, x, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
                 for (int m = 0; m < c.num_dilations; ++m) {
                     const int d = c.resblock_dilations[m];
+                    const bool use_narrow1 = narrow_ok && rb.c1[m].wn && conv_narrow_ok(ch, rb.k, d);
+                    const bool use_narrow2 = narrow_ok && rb.c2[m].wn && conv_narrow_ok(ch, rb.k, 1);
+                    const int planar1 = implicit && !use_narrow1 && rb.c1[m].split, planar2 = implicit && !use_narrow2 && rb.c2[m].split;
                     hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rj, acti, L, ch, rb.act[2 * m].alpha,
-                                       rb.act[2 * m].beta, v->fu, v->fd);
+                                       rb.act[2 * m].beta, v->fu, v->fd, planar1);
                     KCHK();
                     HIPCHK(conv(rb.c1[m], rb.k, d, EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
                     hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, t1, acti, L, ch, rb.act[2 * m + 1].alpha,
-                                       rb.act[2 * m + 1].beta, v->fu, v->fd);
+                                       rb.act[2 * m + 1].beta, v->fu, v->fd, planar2);
                     KCHK();
                     // x_j = x_j + (conv2(.) + bias): residual epilogue, in place
                     HIPCHK(conv(rb.c2[m], rb.k, 1, EpiGateRes{rj, rj, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
@@ -625,7 +630,7 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             KCHK();
         }
         hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
-                           v->fu, v->fd);
+                           v->fu, v->fd, 0);
         hipLaunchKernelGGL(bv_post_kernel, dim3(ew_blocks(L)), dim3(256), 0, s, act, v->post_w, v->post_b, wav + (size_t)b * Lout, L, ch,
                            c.use_tanh_at_final);
         KCHK();

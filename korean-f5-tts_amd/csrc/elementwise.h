@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         int ldo, int R, int D, float eps, const float* __restrict__ A,
                                                         const float* __restrict__ Bv, int vec_stride,
                                                         int rows_per_batch, int modulate, Prefetch pf,
-                                                        const int* __restrict__ m_limit = nullptr) {
+                                                        const int* __restrict__ m_limit = nullptr, int planar = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R || (m_limit && r >= *m_limit)) return;   // (m_limit: rows present in a packed batch, RowPack)
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float4 a = ga[i];
             const float4 b = gb[i];
             if (modulate) { a.x += 1.f; a.y += 1.f; a.z += 1.f; a.w += 1.f; }
-            store4(out + (size_t)r * ldo + c, (v[i].x - mean) * rstd * a.x + b.x, (v[i].y - mean) * rstd * a.y + b.y,
-                   (v[i].z - mean) * rstd * a.z + b.z, (v[i].w - mean) * rstd * a.w + b.w);
+            store4_at(out + (size_t)r * ldo, c, planar, (v[i].x - mean) * rstd * a.x + b.x, (v[i].y - mean) * rstd * a.y + b.y,
+                      (v[i].z - mean) * rstd * a.z + b.z, (v[i].w - mean) * rstd * a.w + b.w);
         }
     }
 #pragma unroll
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // x_transformers.RMSNorm as used by UNetT (unett.py:154,168,185): F.normalize(x, dim=-1) * sqrt(D) * g
 template <typename TO>
 __global__ __launch_bounds__(256) void xrmsnorm_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo,
-                                                       int R, int D, const float* __restrict__ gvec) {
+                                                       int R, int D, const float* __restrict__ gvec, int planar = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void xrmsnorm_kernel(const float* __restrict__
         const int c = lane * 4 + i * 256;
         if (c < D) {
             const float4 gg = *reinterpret_cast<const float4*>(gvec + c);
-            store4(out + (size_t)r * ldo + c, v[i].x * sc * gg.x, v[i].y * sc * gg.y, v[i].z * sc * gg.z, v[i].w * sc * gg.w);
+            store4_at(out + (size_t)r * ldo, c, planar, v[i].x * sc * gg.x, v[i].y * sc * gg.y, v[i].z * sc * gg.z, v[i].w * sc * gg.w);
         }
     }
 }

@@ -31,8 +31,10 @@ template <typename T, bool BB> static int maybe_split_weight(f5_engine* e, hipSt
 // every backbone GEMM goes through here (the time / text paths call launch_gemm<float> directly: always plain f32)
 template <typename T, typename Epi>
 static hipError_t egemm(const f5_engine* e, hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
-                        int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0) {
-    return launch_gemm<T>(s, A, lda, W, ldw, M, N, K, epi, force_cfg, m_limit, m_hint, GemmConv{}, std::is_same_v<T, float> && e->split16);
+                        int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0, bool a_planar = false) {
+    // a_planar: the A operand was written pre-split by its producer (store4_planar: LayerNorm, attention, the GELU epilogue)
+    const int split = (std::is_same_v<T, float> && e->split16) ? (a_planar ? 2 : 1) : 0;
+    return launch_gemm<T>(s, A, lda, W, ldw, M, N, K, epi, force_cfg, m_limit, m_hint, GemmConv{}, split);
 }
 
 // W [N, K] f32 -> T [N, round_up(K, 8)]
@@ -368,6 +370,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
+    const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh are written pre-split (the A operands of the block GEMMs)
     // weight prefetch from the LayerNorm launches (see layernorm_kernel): only where the GEMMs are latency-bound
     const bool wpf = rows <= 4096 && !(getenv("F5_WEIGHT_PREFETCH") && getenv("F5_WEIGHT_PREFETCH")[0] == '0');
     for (int l = 0; l < c.depth; ++l) {
@@ -377,45 +380,45 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
                            m + D, m, mod_stride, N, 1,
                            wpf ? Prefetch{(const char*)bw.qkv.w, (size_t)3 * inner * bw.qkv.ldw * sizeof(T),
-                                          (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{}, ml);
+                                          (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{}, ml, pl);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
-                              -1, ml, mh));
+                              -1, ml, mh, pl));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml, mh));
+                              EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml, mh, pl));
         pr.end(s);
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f,
                            m + 4 * D, m + 3 * D, mod_stride, N, 1,
                            wpf ? Prefetch{(const char*)bw.ff1.w, (size_t)F * bw.ff1.ldw * sizeof(T),
-                                          (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{}, ml);
+                                          (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{}, ml, pl);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(F, D));
-        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}, -1, ml, mh));
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH, pl}, -1, ml, mh, pl));
         pr.end(s);
         pr.begin(PC_GEMM, s, gflops(D, F));
         HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
-                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh));
+                              EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh, pl));
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
     pr.begin(PC_LN, s);
     hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f, mf,
-                       mf + D, mod_stride, N, 1, Prefetch{}, ml);
+                       mf + D, mod_stride, N, 1, Prefetch{}, ml, pl);
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gflops(mel, D));
     HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
-                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml, mh));
+                          EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml, mh, pl));
     pr.end(s);
     return F5_OK;
 }
@@ -458,6 +461,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;   // lens_dev holds len + 1 for UNetT
     const int half = c.depth / 2;
+    const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh written pre-split (as in run_dit_forward)
     for (int l = 0; l < c.depth; ++l) {
         BlockW<T>& bw = P.blocks[l];
         if (l < half) {
@@ -475,37 +479,38 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             pr.end(s);
         }
         pr.begin(PC_LN, s);
-        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g);
+        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g, pl);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()}));
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()},
+                              -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16, pl));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
         HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, nullptr, 0, Nt, lens_dev}));
+                              EpiGateRes{w.x, w.x, D, bw.out.b, nullptr, 0, Nt, lens_dev}, -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_LN, s);
-        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm2_g);
+        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm2_g, pl);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, F, D));
-        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH}));
+        HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH, pl}, -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, F));
-        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}));
+        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}, -1, nullptr, 0, pl));
         pr.end(s);
     }
     pr.begin(PC_LN, s);
-    hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, P.norm_out_g);
+    hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, P.norm_out_g, pl);
     KCHK();
     pr.end(s);
     pr.begin(PC_GEMM, s, gfl(rows, mel, D));
-    HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}));
+    HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}, -1, nullptr, 0, pl));
     pr.end(s);
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL(strip_first_token_kernel, dim3(ew_blocks((long)rows_in * mel / 4)), dim3(256), 0, s, w.pred_all, w.pred, Bp, N, mel);

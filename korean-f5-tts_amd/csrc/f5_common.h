@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the F5-TTS engine.
 // Wave = 64 lanes everywhere; MFMA tiles are 16x16 (bf16 / f16: 16x16x32, f32: 16x16x4).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -66,6 +67,37 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
 __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
     f16x4 v = {(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
     *reinterpret_cast<f16x4*>(p) = v;
+}
+
+// ---- F5_PREC_F16X3 helpers: x = hi + lo with hi = f16(x), lo = f16(x - hi) (gemm2.h MODE 3, attn.h) ----
+__device__ __forceinline__ void split4_f16(const u32x4& c, u32x2& hi, u32x2& lo) {
+    typedef __attribute__((ext_vector_type(2))) float v2f;
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2h;
+    const f32x4 x = __builtin_bit_cast(f32x4, c);
+    const v2f a{x[0], x[1]}, b{x[2], x[3]};
+    const v2h ah = __builtin_convertvector(a, v2h), bh = __builtin_convertvector(b, v2h);
+    const v2h al = __builtin_convertvector(a - __builtin_convertvector(ah, v2f), v2h);
+    const v2h bl = __builtin_convertvector(b - __builtin_convertvector(bh, v2f), v2h);
+    hi = u32x2{__builtin_bit_cast(unsigned, ah), __builtin_bit_cast(unsigned, bh)};
+    lo = u32x2{__builtin_bit_cast(unsigned, al), __builtin_bit_cast(unsigned, bl)};
+}
+// Elements col .. col+3 (col % 4 == 0) of an f32 row stored ALREADY SPLIT, in the layout the split-operand GEMM reads (the same
+// 128 bytes per 32 elements as split_planar_kernel gives the weights: chunk g = hi of k = 4g..4g+3, 16+4g..16+4g+3, chunk 4+g = lo):
+// the producer of a GEMM A operand (LayerNorm, attention, the GELU epilogue) pays the split once instead of every wave that
+// reads the fragment.  `row` must be 128-byte aligned (ld % 32 == 0).
+__device__ __forceinline__ void store4_planar(float* row, int col, float a, float b, float c, float d) {
+    u32x2 hi, lo;
+    split4_f16(__builtin_bit_cast(u32x4, f32x4{a, b, c, d}), hi, lo);
+    const int kk = col & 31;
+    char* p = reinterpret_cast<char*>(row + (col & ~31)) + ((kk & 15) >> 2) * 16 + (kk >> 4) * 8;
+    *reinterpret_cast<u32x2*>(p) = hi;
+    *reinterpret_cast<u32x2*>(p + 64) = lo;
+}
+template <typename TO> __device__ __forceinline__ void store4_at(TO* row, int col, int planar, float a, float b, float c, float d) {
+    if constexpr (std::is_same_v<TO, float>) {
+        if (planar) { store4_planar(row, col, a, b, c, d); return; }
+    }
+    store4(row + col, a, b, c, d);
 }
 
 // eight f32 -> one 16-byte MFMA operand fragment of 16-bit type T

@@ -64,6 +64,7 @@ struct NoCtx {};
 // launchers rewrite it to the static form through with_static_act().
 template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     TO* out; int ldo; const float* bias; int act;
+    int planar = 0;      // TO = float only: store pre-split for the next GEMM's A operand (f5_common.h store4_planar)
     struct RowCtx { TO* p; };
     struct ColCtx { float4 b; int n; };
     typedef NoCtx TRowCtx;
@@ -78,8 +79,8 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
     __device__ __forceinline__ NoCtx preload(const RowCtx&, const ColCtx&) const { return {}; }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v, const NoCtx&) const {
         const int a = ACT >= 0 ? ACT : act;
-        store4(r.p + c.n, apply_act(v[0] + c.b.x, a), apply_act(v[1] + c.b.y, a), apply_act(v[2] + c.b.z, a),
-               apply_act(v[3] + c.b.w, a));
+        store4_at(r.p, c.n, planar, apply_act(v[0] + c.b.x, a), apply_act(v[1] + c.b.y, a), apply_act(v[2] + c.b.z, a),
+                  apply_act(v[3] + c.b.w, a));
     }
     __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
     __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
@@ -90,12 +91,12 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
 template <typename Epi, typename F> inline hipError_t with_static_act(const Epi& e, F&& f) { return f(e); }
 template <typename TO, typename F> inline hipError_t with_static_act(const EpiStore<TO, -1>& e, F&& f) {
     switch (e.act) {
-        case F5_ACT_NONE: return f(EpiStore<TO, F5_ACT_NONE>{e.out, e.ldo, e.bias, e.act});
-        case F5_ACT_GELU_TANH: return f(EpiStore<TO, F5_ACT_GELU_TANH>{e.out, e.ldo, e.bias, e.act});
-        case F5_ACT_GELU_ERF: return f(EpiStore<TO, F5_ACT_GELU_ERF>{e.out, e.ldo, e.bias, e.act});
-        case F5_ACT_SILU: return f(EpiStore<TO, F5_ACT_SILU>{e.out, e.ldo, e.bias, e.act});
-        case F5_ACT_MISH: return f(EpiStore<TO, F5_ACT_MISH>{e.out, e.ldo, e.bias, e.act});
-        case F5_ACT_LOGCLAMP: return f(EpiStore<TO, F5_ACT_LOGCLAMP>{e.out, e.ldo, e.bias, e.act});
+        case F5_ACT_NONE: return f(EpiStore<TO, F5_ACT_NONE>{e.out, e.ldo, e.bias, e.act, e.planar});
+        case F5_ACT_GELU_TANH: return f(EpiStore<TO, F5_ACT_GELU_TANH>{e.out, e.ldo, e.bias, e.act, e.planar});
+        case F5_ACT_GELU_ERF: return f(EpiStore<TO, F5_ACT_GELU_ERF>{e.out, e.ldo, e.bias, e.act, e.planar});
+        case F5_ACT_SILU: return f(EpiStore<TO, F5_ACT_SILU>{e.out, e.ldo, e.bias, e.act, e.planar});
+        case F5_ACT_MISH: return f(EpiStore<TO, F5_ACT_MISH>{e.out, e.ldo, e.bias, e.act, e.planar});
+        case F5_ACT_LOGCLAMP: return f(EpiStore<TO, F5_ACT_LOGCLAMP>{e.out, e.ldo, e.bias, e.act, e.planar});
         default: return hipErrorInvalidValue;
     }
 }

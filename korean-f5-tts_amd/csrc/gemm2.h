@@ -300,7 +300,9 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
 #pragma unroll
                 for (int i = 1; i < MI; ++i) lds_read_b128_asm(af[kk][i], sbu + a_row_off + i * 16 * GEMM_ROW_BYTES + co);
             }
-            if constexpr (MODE == 3) {
+            // MODE 5: the A operand is ALREADY split in memory (store4_planar by its producer): its two fragment reads are hi and lo.
+            // (6, 7: tools/probe/gemm_split_probe.hip -- 2 of 3 / 1 of 3 MFMAs)
+            if constexpr (MODE == 3 || MODE >= 5) {
                 // row i needs both halves of a[i] and (i == 0) every w fragment: the last of them is read (MI + NJ) + NJ + i
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
@@ -312,11 +314,12 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
                         for (int j = 0; j < NJ; ++j) tie<0>(wf[0][j]);
                     }
                     f16x8 ah, al;
-                    split8_f16(af[0][i], af[1][i], ah, al);
+                    if constexpr (MODE == 5) { ah = __builtin_bit_cast(f16x8, af[0][i]); al = __builtin_bit_cast(f16x8, af[1][i]); }
+                    else split8_f16(af[0][i], af[1][i], ah, al);
                     // term-major: consecutive MFMAs write different accumulators (a dependent MFMA waits out the whole
                     // pipeline of its predecessor)
 #pragma unroll
-                    for (int term = 0; term < 3; ++term) {
+                    for (int term = (MODE == 6 ? 1 : MODE == 7 ? 2 : 0); term < 3; ++term) {
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
                             const f16x8 w = __builtin_bit_cast(f16x8, wf[term == 0 ? 1 : 0][j]);   // lo hi hi

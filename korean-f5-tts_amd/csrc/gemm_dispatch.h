@@ -39,9 +39,19 @@ inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
 
 template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
-                                 const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}, bool split = false) {
+                                 const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}, int split = 0) {
     if constexpr (std::is_same_v<T, float>) {
-        if (split) {   // W in the split_planar layout, products on the f16 pipe (gemm2.h MODE 3)
+        if (split == 2) {   // both operands pre-split (gemm2.h MODE 5)
+            switch (cfg) {
+                case G3_256x256_PP:
+                case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                case G2_128x64_8W: return launch_gemm2_cfg<T, 128, 64, 4, 2, 4, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+                default: return launch_gemm2_cfg<T, 64, 64, 2, 2, 3, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
+            }
+        }
+        if (split) {   // W in the split_planar layout, A f32 split in registers, products on the f16 pipe (gemm2.h MODE 3)
             switch (cfg) {
                 case G3_256x256_PP:
                 case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 3>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
@@ -66,7 +76,7 @@ inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W,
 template <typename T, typename Epi>
 inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                               const Epi& epi, int force_cfg = -1, const int* m_limit = nullptr, int m_hint = 0,
-                              const GemmConv& cv = GemmConv{}, bool split = false) {
+                              const GemmConv& cv = GemmConv{}, int split = 0) {   // split: 0 plain, 1 W pre-split, 2 A and W pre-split
     if (M <= 0 || N <= 0) return hipSuccess;
     if (split && (K % (GEMM_ROW_BYTES / (int)sizeof(T)) != 0 || force_cfg == -2)) return hipErrorInvalidValue;   // split operands: v2 kernels only
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);

@@ -14,9 +14,9 @@ static float run(const float* q, const float* k, const float* v, float* o, int B
     dim3 grid(H * Bp, (N + NW * 16 * QS - 1) / (NW * 16 * QS));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((attn_split_fwd_kernel<QS, NW, DIAG>), grid, dim3(NW * 64), smem, 0, q, k, v, o, H, N, N, nullptr, 1, nullptr, nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((attn_split_fwd_kernel<QS, NW, DIAG>), grid, dim3(NW * 64), smem, 0, q, k, v, o, H, N, N, nullptr, 1, nullptr, nullptr, 0);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((attn_split_fwd_kernel<QS, NW, DIAG>), grid, dim3(NW * 64), smem, 0, q, k, v, o, H, N, N, nullptr, 1, nullptr, nullptr);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((attn_split_fwd_kernel<QS, NW, DIAG>), grid, dim3(NW * 64), smem, 0, q, k, v, o, H, N, N, nullptr, 1, nullptr, nullptr, 0);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
