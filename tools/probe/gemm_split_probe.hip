@@ -34,6 +34,14 @@ int main(int argc, char** argv) {
     const double gf = 2.0 * M * N * K * 1e-6;
     printf("M=%d N=%d K=%d (us, TFLOP/s as if all three terms ran)\n", M, N, K);
 #define ROW(BM, BN, WM, WN, NS, MODE, what) { float us = run<BM, BN, WM, WN, NS, MODE>(A, W, O, M, N, K, 30); printf("%dx%d %-38s %8.1f  %7.1f\n", BM, BN, what, us, gf / us); }
+    if (argc > 4) {   // tile sweep with both operands pre-split (MODE 5), as the engine runs the block GEMMs
+        ROW(256, 128, 4, 2, 3, 5, "[13] pre-split")
+        ROW(128, 192, 2, 4, 3, 5, "[10] pre-split")
+        ROW(128, 128, 2, 4, 4, 5, "[2] pre-split")
+        ROW(128, 64, 4, 2, 4, 5, "[9] pre-split")
+        ROW(64, 64, 2, 2, 3, 5, "[8] pre-split")
+        return 0;
+    }
     ROW(256, 128, 4, 2, 3, 0, "f32 MFMA")
     ROW(256, 128, 4, 2, 3, 3, "split, full")
     ROW(256, 128, 4, 2, 3, 5, "split, A not converted")
