@@ -49,6 +49,8 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     if ((2 * c->mel_dim + c->text_dim) % 4) return fail(F5_EINVAL, "2*mel_dim + text_dim must be a multiple of 4");
     if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16 && c->precision != F5_PREC_F16 && c->precision != F5_PREC_F16X3)
         return fail(F5_EINVAL, "bad precision");
+    if (c->precision == F5_PREC_F16X3 && c->ff_dim % 32)
+        return fail(F5_EINVAL, "F5_PREC_F16X3 needs ff_dim %% 32 == 0 (whole 32-element blocks of the split operand layout; got %d)", c->ff_dim);
     if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return fail(F5_EINVAL, "bad backbone");
     if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2)) return fail(F5_EINVAL, "UNetT depth must be even");
     if (c->text_dim > 2048 || c->dim > 2048) return fail(F5_EINVAL, "dims > 2048 unsupported");

@@ -94,7 +94,8 @@ __device__ __forceinline__ void split8_f16(const u32x4& c0, const u32x4& c1, f16
         lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
     }
 }
-template <int N> __device__ __forceinline__ void tie(u32x4& a) { asm volatile("" : "+v"(a)); }
+// orders a fragment register behind the hand-placed lgkmcnt wait that precedes it (no instruction is emitted)
+__device__ __forceinline__ void tie(u32x4& a) { asm volatile("" : "+v"(a)); }
 
 // Implicit-GEMM Conv1d over a time-major [rows, C] activation (BigVGAN's dilated convolutions, bigvgan.hip): K index
 // tap * C + ci of the tap-major weight operand multiplies A[row + (tap - half) * dil][ci], so K-tile kt of the A operand
@@ -308,10 +309,10 @@ __device__ __forceinline__ void gemm_tn_glds_body(char* smem, const T* __restric
                 for (int i = 0; i < MI; ++i) {
                     __builtin_amdgcn_sched_barrier(0);
                     wait_row<R, MI, NJ>(1, i, af, wf);
-                    tie<0>(af[0][i]);
+                    tie(af[0][i]);
                     if (i == 0) {
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) tie<0>(wf[0][j]);
+                        for (int j = 0; j < NJ; ++j) tie(wf[0][j]);
                     }
                     f16x8 ah, al;
                     if constexpr (MODE == 5) { ah = __builtin_bit_cast(f16x8, af[0][i]); al = __builtin_bit_cast(f16x8, af[1][i]); }

@@ -63,7 +63,9 @@ inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W,
         }
     } else if (split) return hipErrorInvalidValue;
     switch (cfg) {
-        case G3_256x256_PP: if (cv.tpt == 0) return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);   // (no conv mode: falls through)
+        case G3_256x256_PP:
+            if (cv.tpt == 0 && cv.m_base == 0) return launch_gemm3<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml);
+            [[fallthrough]];   // (the ping-pong kernel has no implicit-conv / row-offset mode)
         case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
         case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
         case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
