@@ -184,13 +184,26 @@ static __global__ __launch_bounds__(256) void bv_conv_narrow_kernel(const float*
     constexpr int TB = 4 * MT * 16;
     const int half = (k - 1) / 2, halo = half * dil, S = C + 1, rows = TB + 2 * halo, c4n = C / 4;
     const long t0 = (long)blockIdx.x * TB;
-    for (int i = threadIdx.x; i < rows * c4n; i += 256) {
-        const int row = i / c4n, col = (i - row * c4n) * 4;
-        const long g = t0 - halo + row;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (g >= 0 && g < L) v = *reinterpret_cast<const float4*>(x + g * C + col);
-        float* d = bv_xs + row * S + col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    // (four loads in flight per thread, from clamped addresses, before their stores: a load-if-in-range / store loop compiles to
+    //  one serialised memory round trip per iteration -- convpos.h)
+    for (int base = threadIdx.x; base < rows * c4n; base += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(base + u * 256, rows * c4n - 1), row = i / c4n, col = (i - row * c4n) * 4;
+            const long g = min(max(t0 - halo + row, 0L), L - 1);
+            v[u] = *reinterpret_cast<const float4*>(x + g * C + col);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 256, row = i / c4n, col = (i - row * c4n) * 4;
+            const long g = t0 - halo + row;
+            const bool in = g >= 0 && g < L;
+            if (i < rows * c4n) {
+                float* d = bv_xs + row * S + col;
+                d[0] = in ? v[u].x : 0.f; d[1] = in ? v[u].y : 0.f; d[2] = in ? v[u].z : 0.f; d[3] = in ? v[u].w : 0.f;
+            }
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;

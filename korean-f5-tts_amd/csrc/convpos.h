@@ -80,13 +80,25 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t) issue(t, t);
 
-    // ---- stage the input window (fp32 -> T) while the first weight tiles are in flight
-    for (int c = tid; c < XR * (CPG / 4); c += 256) {
-        const int row = c / (CPG / 4), c4 = c % (CPG / 4);
+    // ---- stage the input window (fp32 -> T) while the first weight tiles are in flight.  ALL of a thread's loads are issued
+    // before the first store, from clamped (always valid) addresses: as a load-if-in-range / store loop hipcc emitted
+    // `global_load; s_waitcnt vmcnt(0); ds_write` per iteration -- ten serialised memory round trips (and a wait for the
+    // weight ring's prologue) before the first MFMA of a 24 us kernel.
+    constexpr int XCH = XR * (CPG / 4), XIT = (XCH + 255) / 256;
+    float4 xv[XIT];
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+        const int c = min(tid + i * 256, XCH - 1), row = c / (CPG / 4), c4 = c % (CPG / 4);
+        const int tok = tok0 - 15 + row, tokc = max(min(tok, len - 1), 0);
+        xv[i] = *reinterpret_cast<const float4*>(X + (rbase + tokc) * D + grp * CPG + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+        const int c = tid + i * 256, row = c / (CPG / 4), c4 = c % (CPG / 4);
         const int tok = tok0 - 15 + row;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (tok >= 0 && tok < len) v = *reinterpret_cast<const float4*>(X + (rbase + tok) * D + grp * CPG + c4 * 4);
-        store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, v.x, v.y, v.z, v.w);
+        const bool in = tok >= 0 && tok < len;      // (rows outside the sequence are zero: conv padding / masked rows)
+        if (c < XCH)
+            store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, in ? xv[i].x : 0.f, in ? xv[i].y : 0.f, in ? xv[i].z : 0.f, in ? xv[i].w : 0.f);
     }
     __syncthreads();   // (also retires the window's global loads, which are older than nothing the ring counts below:
                        //  the compiler waits vmcnt(0) for them, i.e. for the first NS-1 weight tiles too -- once)
