@@ -36,8 +36,8 @@ extern "C" {
 #define F5_PREC_F16 2    /* fp16 MFMA operands (the reference's own GPU dtype, infer/utils_infer.py:243-251; same MFMA rate as
                             bf16, 3 more mantissa bits), f32 accumulate, f32 residual stream / ODE state / norms */
 #define F5_PREC_F16X3 3  /* f32 data flow (activations, attention, norms as F5_PREC_F32); each GEMM operand is split into two fp16
-                            halves (hi + lo, 22 bits) and the product takes three fp16 MFMAs: f32-level results at ~1/5 of the
-                            f32 MFMA time.  |activation| < 65504 as for F5_PREC_F16 */
+                            halves (hi + lo, 22 bits) and the product takes three fp16 MFMAs: f32-level results; the backbone GEMMs run
+                            at ~2.5-3x the f32 MFMA rate, a C2 utterance in 0.46x the f32 time.  |activation| < 65504 as for F5_PREC_F16 */
 
 #define F5_BACKBONE_DIT 0
 #define F5_BACKBONE_UNETT 1

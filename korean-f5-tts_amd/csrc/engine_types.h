@@ -1,6 +1,7 @@
 // Engine state shared by the translation units of libf5hip.so: containers, packed weights, the f5_engine handle, the
 // per-call workspace and the per-precision entry points (EngineOps<T>, instantiated once per operand type in
-// engine_bf16.hip / engine_f16.hip / engine_f32.hip so that the three precisions compile in parallel).
+// engine_bf16.hip / engine_f16.hip / engine_f32.hip so that the precisions compile in parallel; F5_PREC_F16X3 is the float
+// instantiation with f5_engine::split16 set).
 #pragma once
 #include <hip/hip_runtime.h>
 
