@@ -97,10 +97,13 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
             return launch_gemm_v2<T, Epi>(s, A + (size_t)main * lda, lda, W, ldw, rem, N, K, epi, G2_64x64_4W, nullptr, tail);
         }
     }
-    if (K % KT == 0 && force_cfg != -2)
-        return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi,
-                                      force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi)),
-                                      m_limit, cv, split);
+    if (K % KT == 0 && force_cfg != -2) {
+        int cfg = force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi));
+        // pre-split operands (F5_PREC_F16X3 block GEMMs): three MFMAs per fragment pair shift the balance towards the small tile
+        // where both fit in two rounds (2048 x 1024 x {1024, 2048}: 64x64 16.2 / 28.7 us, 128x64 18.0 / 30.8 -- tools/probe/gemm_split_probe.hip)
+        if (split == 2 && force_cfg < 0 && cfg == G2_128x64_8W && (long)((M + 63) / 64) * ((N + 63) / 64) <= 512) cfg = G2_64x64_4W;
+        return launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, M, N, K, epi, cfg, m_limit, cv, split);
+    }
     if (m_limit) return hipErrorInvalidValue;
     return launch_gemm_v1<T, Epi>(s, A, lda, W, ldw, M, N, K, epi);
 }
