@@ -15,7 +15,8 @@ enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_
 // tools/gemm2_sweep.py on a full chip: the per-K-step time grows much more slowly than the tile area, so the largest
 // tile that does not add a round wins; e.g. the QKV projection 2048 x 3072: 128x128 = 384 tiles = 2 rounds (25 us),
 // 128x192 = 256 tiles = 1 round (20 us)).
-inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
+// g3_penalty: extra us per round for the ping-pong tile when the epilogue is memory-heavy (see launch_gemm)
+inline int pick_cfg_v2(int M, int N, bool allow_v3 = false, float g3_penalty = 0.f) {
     static const int forced = getenv("F5_GEMM_CFG") ? atoi(getenv("F5_GEMM_CFG")) : -1;   // diagnostic: one tile for every GEMM
     static const int forced_n = getenv("F5_GEMM_CFG_N") ? atoi(getenv("F5_GEMM_CFG_N")) : 0;   // ... only for this N
     if (forced >= 0 && (forced != G3_256x256_PP || allow_v3) && (forced_n == 0 || forced_n == N)) return forced;
@@ -31,11 +32,14 @@ inline int pick_cfg_v2(int M, int N, bool allow_v3 = false) {
     for (const Cand& c : cands) {
         if (c.id == G3_256x256_PP && !allow_v3) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
-        const float cost = (float)((tiles + 255) / 256) * c.t;
+        const float cost = (float)((tiles + 255) / 256) * (c.t + (c.id == G3_256x256_PP ? g3_penalty : 0.f));
         if (cost < best_cost) { best_cost = cost; best = c.id; }  // ties keep the larger tile (listed first)
     }
     return best;
 }
+
+template <typename Epi> inline bool epilogue_streams_residual(const Epi&) { return false; }
+inline bool epilogue_streams_residual(const EpiGateRes&) { return true; }
 
 template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
@@ -87,10 +91,15 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     // A many-row problem whose row count is a few rows past a multiple of 256 (UNetT: 16 x 1025 = 16,400 rows) would pay
     // a whole extra round of 256-row tiles for the last 16 rows: the 256-row multiple goes to the ping-pong kernel and the
     // remainder to one row of 64x64 tiles (same K order per element: bit-identical to a single launch).
+    // The residual epilogue (EpiGateRes) reads and writes the f32 stream: 128 MB per launch at 16,384 rows, which a single round
+    // of 256x256 tiles cannot overlap with anything; two rounds of 256x128 tiles overlap the first round's stores with the
+    // second round's K loop (C3, same box: 1,433 -> 1,408 ms).  Expressed as a per-round penalty on the ping-pong tile.
+    const float g3_pen = epilogue_streams_residual(epi) ? 6.0f : 0.0f;
     if (K % KT == 0 && force_cfg == -1 && !m_limit && cv.tpt == 0 && !split && sizeof(T) == 2 && gemm3_epilogue_ok(epi)) {
         const int rem = M % 256, main = M - rem;
-        if (rem > 0 && rem <= 64 && main >= 4096 && pick_cfg_v2(main, N, true) == G3_256x256_PP) {
-            hipError_t e = launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, main, N, K, epi, G3_256x256_PP);
+        const int cfg_main = (rem > 0 && rem <= 64 && main >= 4096) ? pick_cfg_v2(main, N, true, g3_pen) : -1;
+        if (cfg_main == G3_256x256_PP || cfg_main == G2_256x128_8W) {
+            hipError_t e = launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, main, N, K, epi, cfg_main);
             if (e != hipSuccess) return e;
             GemmConv tail{};
             tail.m_base = main;
@@ -98,7 +107,7 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
         }
     }
     if (K % KT == 0 && force_cfg != -2) {
-        int cfg = force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi));
+        int cfg = force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi), g3_pen);
         // pre-split operands (F5_PREC_F16X3 block GEMMs): three MFMAs per fragment pair shift the balance towards the small tile
         // where both fit in two rounds (2048 x 1024 x {1024, 2048}: 64x64 16.2 / 28.7 us, 128x64 18.0 / 30.8 -- tools/probe/gemm_split_probe.hip)
         if (split == 2 && force_cfg < 0 && cfg == G2_128x64_8W && (long)((M + 63) / 64) * ((N + 63) / 64) <= 512) cfg = G2_64x64_4W;
