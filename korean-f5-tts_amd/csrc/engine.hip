@@ -17,8 +17,6 @@
 //
 // This file: the C ABI and the precision-independent host logic.  The kernels and the per-call graph of launches are
 // templates over the MFMA operand type (engine_impl.h), instantiated in engine_{bf16,f16,f32}.hip.
-#include <cmath>
-
 #include "engine_types.h"
 
 // precision dispatch of one EngineOps<T> member
@@ -132,39 +130,19 @@ extern "C" int f5_reserve(f5_engine* e, int32_t B, int32_t N, int32_t S) {
 // Infinity Cache between the kernels of a block, instead of streaming every intermediate through HBM (C3: 65,536 rows).
 // F5_CHUNK_ROWS overrides the row budget (tests force tiny chunks).
 // With row packing (RowPack) an utterance costs its own length, not the padded one: the budget then counts the rows
-// actually present (C3: 3 chunks of 11 utterances ~ 15,500 rows instead of 4 x 8 padded to 16,384 of which 11,300 exist).
+// actually present (C3 with attn_mask_enabled: 2 chunks of 16 utterances ~ 22,600 valid rows each).
 int chunk_utts(f5_engine* e, int B, int N, bool use_cfg, const int32_t* lens_host) {
     if (split_cfg_enabled(e)) return B;   // the opt-in two-stream mode steps the whole batch per half
-    const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 20000;   // (C3: 4,096 / 8,192 / 16,384 / 32,768 / all rows -> 1.76 / 1.53 / 1.48 / 1.55 / 1.58 s)
+    // Budget 32,768 rows, equal chunks.  C3 (65,536 rows) on one box, end of round 2: 4 x 16,384 rows 1,460 ms, 3 x 21,845 1,515 (every
+    // GEMM pays a mostly empty last round of tiles), 2 x 32,768 **1,435**, 1 x 65,536 1,447; with packed rows (45,200 valid) 3 chunks
+    // 1,189, 2 chunks **1,113**.  (A model that counted rounds of 256x256 tiles per chunk preferred 3 packed chunks: removed.  Earlier
+    // in the round, before the residual GEMMs moved to two rounds of 256x128 tiles, 16,384 rows was the optimum: 1.48 vs 1.55 s.)
+    const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 32768;
     long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
     if (lens_host && pack_rows_enabled(e)) {
         long total = 0;
         for (int i = 0; i < B; ++i) total += (lens_host[i] + 3) / 4 * 4;
         rows_per_utt = std::max(1L, (long)(use_cfg ? 2 : 1) * total / B);
-    }
-    if (!getenv("F5_CHUNK_ROWS") && (long)B * rows_per_utt > 16384) {
-        // Many rows: the block GEMMs run on 256x256 tiles (gemm3.h), 256 at a time, so their time moves in whole ROUNDS of
-        // tiles: 19,800 rows are 78 row tiles = 312 tiles of the out-projection = two rounds where 1.2 would do.  Choose the
-        // number of equal chunks (8,192 .. 24,576 rows each: large enough for those tiles, small enough for the cache) that
-        // minimises  chunks x sum over the block's GEMMs of (K / 1024) x rounds;  ties go to fewer, larger chunks.
-        // C3 (32 x 2,048 rows): 3 / 4 / 5 chunks cost 42 / 32 / 40 -> 4 x 8 utterances, the measured optimum above.
-        const f5_config& c = e->cfg;
-        const int D = c.dim, inner = e->inner, F = c.ff_dim;
-        const double gn[5] = {3.0 * inner, (double)D, (double)F, (double)D, (double)D};
-        const double gk[5] = {(double)D, (double)inner, (double)D, (double)F, c.backbone == F5_BACKBONE_UNETT ? 1.0 * D : 0.0};   // (skip GEMM: K = 2D on half the layers)
-        const long total = (long)B * rows_per_utt;
-        const long nc_lo = std::max(1L, (total + 24575) / 24576), nc_hi = std::min<long>(B, std::max(nc_lo, total / 8192));
-        double best = 1e300;
-        long best_per = B;
-        for (long nc = nc_lo; nc <= nc_hi; ++nc) {
-            const long per = (B + nc - 1) / nc, chunks = (B + per - 1) / per, rows = per * rows_per_utt;
-            const long rt = rows / 256 + (rows % 256 > 64 ? 1 : 0);      // (a remainder of <= 64 rows runs apart: launch_gemm)
-            double cost = 0;
-            for (int g = 0; g < 5; ++g) cost += gk[g] / 1024.0 * (double)((long)(rt * std::ceil(gn[g] / 256.0) + 255) / 256);
-            cost *= (double)chunks;
-            if (cost < best - 1e-9) { best = cost; best_per = per; }
-        }
-        return (int)best_per;
     }
     long bc = budget / rows_per_utt;
     if (bc < 1) bc = 1;

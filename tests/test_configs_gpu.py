@@ -2,9 +2,9 @@
 reach the tile shapes, chunking and grid sizes these engage):
 
   C2  F5-TTS Base, B=1, 256 + 768 frames, NFE=16 EPSS, cfg 2, sway -1   -- every precision against the CPU oracle
-  C3  F5-TTS Base, variable-length padded batch: 16 utterances x 1 Euler step against the oracle with the engine's default
-      row budget (two chunks of 8 utterances = 16,384 rows: C3's own chunk geometry and GEMM tiles), then the full
-      B=32 / NFE=32 job through size-independent properties
+  C3  F5-TTS Base, variable-length padded batch: 16 utterances x 1 Euler step against the oracle, stepped as two chunks of 8
+      utterances = 16,384 rows (many-row GEMM tiles, chunk-major tables), then the full B=32 / NFE=32 job (default budget: two
+      chunks of 16 utterances = 32,768 rows) through size-independent properties
   C5  E2-TTS Base (UNetT, 24 layers, time token prepended: N + 1 = 1025 tokens), B=8
 
 The oracle (oracle/f5_oracle.py, pinned against the reference in this repository's CPU tests) is the checker; it needs
@@ -78,12 +78,12 @@ def test_c2_size_every_precision_vs_oracle():
         assert errs[prec][0] < TOL_C2[prec]
 
 
-def test_c3_chunked_base_batch_vs_oracle():
-    """16 ragged utterances (384 .. 1024 frames, the longest first as in bench.py) at Base dims with F5_CHUNK_ROWS at its
-    default: the ODE state is stepped as two chunks of 8 utterances (16,384 rows each: 256x128 GEMM tiles, chunk-major
-    length table, per-chunk CFG halves), exactly the geometry of C3's four chunks.  One Euler step against the oracle."""
+def test_c3_chunked_base_batch_vs_oracle(monkeypatch):
+    """16 ragged utterances (384 .. 1024 frames, the longest first as in bench.py) at Base dims with a 16,384-row budget: the
+    ODE state is stepped as two chunks of 8 utterances (many-row GEMM tiles, chunk-major length table, per-chunk CFG halves).
+    One Euler step against the oracle.  (The default budget, 32,768 rows, would take these 16 utterances in one chunk.)"""
     _threads()
-    assert "F5_CHUNK_ROWS" not in os.environ
+    monkeypatch.setenv("F5_CHUNK_ROWS", "16384")
     arch = P.config.F5TTS_BASE
     sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
     gl = torch.Generator().manual_seed(1234)
@@ -111,7 +111,7 @@ def test_c3_chunked_base_batch_vs_oracle():
 
 def test_c3_full_job_properties(monkeypatch):
     """The whole C3 job (B=32, N <= 1024, NFE=32): bit-determinism in the benchmarked precision; f32 chunked (default
-    budget: 4 chunks of 8) == unchunked to rounding; every item's prompt returned verbatim."""
+    budget: 2 chunks of 16) == unchunked to rounding; every item's prompt returned verbatim."""
     arch = P.config.F5TTS_BASE
     sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
     gl = torch.Generator().manual_seed(1234)
@@ -133,7 +133,7 @@ def test_c3_full_job_properties(monkeypatch):
     monkeypatch.setenv("F5_CHUNK_ROWS", "100000000")   # one chunk: all 65,536 rows per forward
     _, tb = _model(P.DiT, arch, sd, "f32").sample(cond, text, torch.tensor(durs), steps=4, **kw)
     d = (ta - tb).abs().max().item()
-    print(f"[C3 full job] f32 chunked (4 x 8 utterances) vs unchunked: traj Linf {d:.3e}")
+    print(f"[C3 full job] f32 chunked (2 x 16 utterances) vs unchunked: traj Linf {d:.3e}")
     assert d < 1e-5
 
 
@@ -142,6 +142,7 @@ def test_c3_attn_mask_packed_rows_match_padded_rows(monkeypatch):
     reference's unpad_input + flash_attn_varlen_func, modules.py:510-531).  At Base dims, 16 ragged utterances in two
     chunks, 2 Euler steps: packed == padded (F5_PACK_ROWS=0, itself pinned against the reference's vectors at small
     dims) on every frame inside a sample's own length; frames past it keep their initial value."""
+    monkeypatch.setenv("F5_CHUNK_ROWS", "20000")      # two chunks each way, of different composition (see below)
     arch = dict(P.config.F5TTS_BASE, attn_mask_enabled=True)
     sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
     gl = torch.Generator().manual_seed(99)
