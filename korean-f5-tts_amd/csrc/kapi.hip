@@ -36,8 +36,12 @@ static int gemm_impl(const float* A, const float* W, const float* bias, int act,
     const bool split = g_split16 && std::is_same_v<T, float>;
     if (split && tm > 0) return fail(F5_EINVAL, "f5k_gemm: the split-operand mode has no v1 kernel");
     HIPCHK(maybe_split<T>(s, w.p, (size_t)N * Kp));
+    // F5_PREC_F16X3 with tn == 5: the A operand pre-split as well (what store4_planar producers hand the block GEMMs: MODE 5)
+    const bool a_planar = split && tm <= 0 && tn == 5;
+    if (a_planar) HIPCHK(maybe_split<T>(s, a.p, (size_t)M * Kp));
     if (tm > 0) HIPCHK(launch_gemm_v1<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm, tn));
-    else HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm < 0 ? -tm : -1, nullptr, 0, GemmConv{}, split));
+    else HIPCHK(launch_gemm<T>(s, a.p, Kp, w.p, Kp, M, N, Kp, EpiStore<float>{out, N, bias, act}, tm < 0 ? -tm : -1, nullptr, 0, GemmConv{},
+                               a_planar ? 2 : (split ? 1 : 0)));
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
 }

@@ -44,6 +44,20 @@ def test_gemm_bias_matches_torch(M, N, K, prec, tol):
     assert rel_err(out, ref_r) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 1024), (300, 100, 1024), (513, 1028, 512), (77, 64, 712)])
+def test_gemm_f16x3_presplit_a_operand_is_bit_identical(M, N, K):
+    """F5_PREC_F16X3: the block GEMMs read an A operand that its producer stored already split (store4_planar -> gemm2.h MODE 5).
+    Splitting in memory or in registers yields the same hi / lo halves, so both kernels must agree bit for bit (every tile)."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    for cfg in (0, -8, -9, -2, -10, -13):
+        in_regs = k_gemm("f16x3", A, W, b, tile=(cfg, 0))
+        in_mem = k_gemm("f16x3", A, W, b, tile=(cfg, 5))
+        assert torch.equal(in_regs, in_mem), cfg
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_gemm_many_rows_with_a_small_remainder_is_split_and_bit_identical(prec):
     """M = 48 x 256 + 16 (UNetT batches: B x 1025 rows): launch_gemm sends the 256-row multiple to the ping-pong kernel and the
