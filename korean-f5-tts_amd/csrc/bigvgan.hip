@@ -622,21 +622,21 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             for (int j = 0; j < c.num_kernels; ++j) {
                 const BRes& rb = v->res[(size_t)i * c.num_kernels + j];
                 float* rj = r + (size_t)j * lc_max;
-                HIPCHK(hipMemcpyAsync(rj, x, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
                 for (int m = 0; m < c.num_dilations; ++m) {
+                    const float* rin = m == 0 ? x : rj;     // the block's input: the first pair reads x itself (no copy into rj)
                     const int d = c.resblock_dilations[m];
                     const bool use_narrow1 = narrow_ok && rb.c1[m].wn && conv_narrow_ok(ch, rb.k, d);
                     const bool use_narrow2 = narrow_ok && rb.c2[m].wn && conv_narrow_ok(ch, rb.k, 1);
                     const int planar1 = implicit && !use_narrow1 && rb.c1[m].split, planar2 = implicit && !use_narrow2 && rb.c2[m].split;
-                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rj, acti, L, ch, rb.act[2 * m].alpha,
+                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rin, acti, L, ch, rb.act[2 * m].alpha,
                                        rb.act[2 * m].beta, v->fu, v->fd, planar1);
                     KCHK();
                     HIPCHK(conv(rb.c1[m], rb.k, d, EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
                     hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, t1, acti, L, ch, rb.act[2 * m + 1].alpha,
                                        rb.act[2 * m + 1].beta, v->fu, v->fd, planar2);
                     KCHK();
-                    // x_j = x_j + (conv2(.) + bias): residual epilogue, in place
-                    HIPCHK(conv(rb.c2[m], rb.k, 1, EpiGateRes{rj, rj, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
+                    // x_j = x_j + (conv2(.) + bias): residual epilogue (in place from the second pair on)
+                    HIPCHK(conv(rb.c2[m], rb.k, 1, EpiGateRes{rj, rin, ch, rb.c2[m].b, nullptr, 0, (int)L + 1, nullptr}));
                 }
             }
             hipLaunchKernelGGL(bv_mean_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, r, (long)lc_max, c.num_kernels, x, cnt / 4);
