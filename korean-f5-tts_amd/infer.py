@@ -120,14 +120,15 @@ def load_model(model_cls, model_cfg: dict, ckpt_path: str | None, mel_spec_type=
     return model.to(device)
 
 
-def load_vocoder(vocoder_name="vocos", is_local=True, local_path="", device="cuda", hf_cache_dir=None):
+def load_vocoder(vocoder_name="vocos", is_local=True, local_path="", device="cuda", hf_cache_dir=None, precision="f32"):
     """utils_infer.py:114-153.  vocos: `pytorch_model.bin` of charactr/vocos-mel-24khz; bigvgan: `bigvgan_generator.pt` of
-    nvidia/bigvgan_v2_24khz_100band_256x ({"generator": state_dict}, weight-norm pairs folded on load)."""
+    nvidia/bigvgan_v2_24khz_100band_256x ({"generator": state_dict}, weight-norm pairs folded on load).
+    precision (bigvgan only; not a reference argument): "f32" or "f16x3" (split-f16 products, f32-level results, ~2x faster)."""
     if not is_local:
         raise RuntimeError("no network in this environment: pass is_local=True and a directory with the vocoder weights")
     if vocoder_name == "bigvgan":
         from .bigvgan import BigVGAN
-        voc = BigVGAN()
+        voc = BigVGAN(precision=precision)
         ck = torch.load(f"{local_path}/bigvgan_generator.pt", map_location="cpu", weights_only=True)
         voc.load_state_dict(ck.get("generator", ck))
         return voc.eval().to(device)
