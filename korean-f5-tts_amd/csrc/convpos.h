@@ -19,7 +19,10 @@
 
 namespace f5 {
 
-template <typename T, int CPG, int NS>
+// SPLIT (T = float, CPG % 32 == 0; F5_PREC_F16X3): products on the f16 pipe with split operands as in gemm2.h MODE 3 -- the weights
+// arrive pre-split (split_planar_kernel: per 32-element K block, which lies inside one tap, chunk g = hi of k = 4g..4g+3,
+// 16+4g..16+4g+3, chunk 4+g = lo), the input window is split once while it is staged (per row: CPG f16 hi, then CPG f16 lo).
+template <typename T, int CPG, int NS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ X, const T* __restrict__ Wp, int Kp,
                                                       const float* __restrict__ bias, const float* __restrict__ res,
                                                       float* __restrict__ Y, int N, int D, const int* __restrict__ lens,
@@ -97,8 +100,17 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         const int c = tid + i * 256, row = c / (CPG / 4), c4 = c % (CPG / 4);
         const int tok = tok0 - 15 + row;
         const bool in = tok >= 0 && tok < len;      // (rows outside the sequence are zero: conv padding / masked rows)
-        if (c < XCH)
-            store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, in ? xv[i].x : 0.f, in ? xv[i].y : 0.f, in ? xv[i].z : 0.f, in ? xv[i].w : 0.f);
+        if (c < XCH) {
+            const float4 v = make_float4(in ? xv[i].x : 0.f, in ? xv[i].y : 0.f, in ? xv[i].z : 0.f, in ? xv[i].w : 0.f);
+            if constexpr (SPLIT) {
+                u32x2 hi, lo;
+                split4_f16(__builtin_bit_cast(u32x4, f32x4{v.x, v.y, v.z, v.w}), hi, lo);
+                *reinterpret_cast<u32x2*>(xs + row * XRS + c4 * 8) = hi;
+                *reinterpret_cast<u32x2*>(xs + row * XRS + CPG * 2 + c4 * 8) = lo;
+            } else {
+                store4(reinterpret_cast<T*>(xs + row * XRS) + c4 * 4, v.x, v.y, v.z, v.w);
+            }
+        }
     }
     __syncthreads();   // (also retires the window's global loads, which are older than nothing the ring counts below:
                        //  the compiler waits vmcnt(0) for them, i.e. for the first NS-1 weight tiles too -- once)
@@ -118,6 +130,32 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         if (pf >= NS) pf -= NS;
         issue(kt + NS - 1, pf);
         const char* Ws = ws + stage * WTILE + l15 * GEMM_ROW_BYTES;
+        if constexpr (SPLIT) {
+            // one 32-deep block of tap `tap`, channels cib .. cib+31: slot order of lane group g = {cib + 4g ..+3, cib + 16 + 4g ..+3}
+            const int kidx = kt * KT, tap = kidx / CPG, cib = kidx - tap * CPG;
+            u32x4 xh[2], xl[2], wh[NJ], wl[NJ];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* xr = xs + (wave * 32 + i * 16 + l15 + tap) * XRS + (cib + 4 * g) * 2;
+                const u32x2 a0 = *reinterpret_cast<const u32x2*>(xr), a1 = *reinterpret_cast<const u32x2*>(xr + 32);
+                const u32x2 b0 = *reinterpret_cast<const u32x2*>(xr + CPG * 2), b1 = *reinterpret_cast<const u32x2*>(xr + CPG * 2 + 32);
+                xh[i] = u32x4{a0.x, a0.y, a1.x, a1.y};
+                xl[i] = u32x4{b0.x, b0.y, b1.x, b1.y};
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                wh[j] = *reinterpret_cast<const u32x4*>(Ws + j * 16 * GEMM_ROW_BYTES + ((g ^ wsw) * 16));
+                wl[j] = *reinterpret_cast<const u32x4*>(Ws + j * 16 * GEMM_ROW_BYTES + (((4 + g) ^ wsw) * 16));
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, term == 0 ? wl[j] : wh[j]),
+                                                                           __builtin_bit_cast(f16x8, term == 1 ? xl[i] : xh[i]), acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             // im2col k index of this lane's 16-byte chunk -> (tap, ci0)
@@ -134,6 +172,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        }
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -167,43 +206,53 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     }
 }
 
-template <typename T, int CPG, int NS>
+template <typename T, int CPG, int NS, bool SPLIT = false>
 inline hipError_t launch_convpos_ns(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
                                     const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl,
                                     const int* row_start) {
     constexpr int smem = NS * CPG * GEMM_ROW_BYTES + (128 + 32) * (CPG * (int)sizeof(T) + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convpos_kernel<T, CPG, NS, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid((N + 127) / 128, D / CPG, Bp);
-    hipLaunchKernelGGL((convpos_kernel<T, CPG, NS>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl, row_start);
+    hipLaunchKernelGGL((convpos_kernel<T, CPG, NS, SPLIT>), grid, dim3(256), smem, s, X, Wp, Kp, bias, res, Y, N, D, lens, nbl, row_start);
     return hipGetLastError();
 }
 
 template <typename T, int CPG>
 inline hipError_t launch_convpos_cpg(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias,
                                      const float* res, float* Y, int Bp, int N, int D, const int* lens, int nbl,
-                                     const int* row_start) {
+                                     const int* row_start, bool split = false) {
     constexpr int KT = GEMM_ROW_BYTES / (int)sizeof(T);
     if (Kp % KT != 0) return hipErrorInvalidValue;   // weights must be padded to whole K-tiles
     const long blocks = (long)((N + 127) / 128) * (D / CPG) * Bp;
+    if constexpr (std::is_same_v<T, float> && CPG % 32 == 0) {
+        if (split) {
+            if (blocks > 384) return launch_convpos_ns<T, CPG, 4, true>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+            return launch_convpos_ns<T, CPG, 8, true>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+        }
+    }
+    if (split) return hipErrorInvalidValue;          // (split weights need the split kernel: float, 32 | channels per group)
     if (blocks > 384) return launch_convpos_ns<T, CPG, 4>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
     return launch_convpos_ns<T, CPG, 8>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
 }
 
-// D/16 channels per group must be 16, 32, 48 or 64 (dim 256 / 512 / 768 / 1024).
+// D/16 channels per group must be 16, 32, 48 or 64 (dim 256 / 512 / 768 / 1024).  split: the weights are pre-split
+// (convpos_can_split(D) only) and the products run on the f16 pipe.
+inline bool convpos_can_split(int D) { return (D / 16) % 32 == 0; }
 template <typename T>
 inline hipError_t launch_convpos(hipStream_t s, const float* X, const T* Wp, int Kp, const float* bias, const float* res,
-                                 float* Y, int Bp, int N, int D, const int* lens, int nbl, const int* row_start = nullptr) {
+                                 float* Y, int Bp, int N, int D, const int* lens, int nbl, const int* row_start = nullptr,
+                                 bool split = false) {
     switch (D / 16) {
-        case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
-        case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
-        case 48: return launch_convpos_cpg<T, 48>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
-        case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start);
+        case 16: return launch_convpos_cpg<T, 16>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start, split);
+        case 32: return launch_convpos_cpg<T, 32>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start, split);
+        case 48: return launch_convpos_cpg<T, 48>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start, split);
+        case 64: return launch_convpos_cpg<T, 64>(s, X, Wp, Kp, bias, res, Y, Bp, N, D, lens, nbl, row_start, split);
         default: return hipErrorInvalidValue;
     }
 }

@@ -28,6 +28,8 @@ template <typename T, bool BB> static int maybe_split_weight(f5_engine* e, hipSt
     }
     return F5_OK;
 }
+// the conv position embedding runs split too where its K blocks stay inside one tap (32 | channels per group: dim 512, 1024)
+static inline bool conv_split(const f5_engine* e) { return e->split16 && convpos_can_split(e->cfg.dim); }
 // every backbone GEMM goes through here (the time / text paths call launch_gemm<float> directly: always plain f32)
 template <typename T, typename Epi>
 static hipError_t egemm(const f5_engine* e, hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
@@ -149,6 +151,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         CHK(dev_alloc(e, &P.conv_w[j], (size_t)D * P.conv_kp));
         hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(ew_blocks((long)D * P.conv_kp)), dim3(256), 0, s, w->p,
                            P.conv_w[j], (long)D, cpg, 31, P.conv_kp);
+        if (conv_split(e)) CHK((maybe_split_weight<T, true>(e, s, P.conv_w[j], (size_t)D * P.conv_kp)));   // F5_PREC_F16X3 (convpos.h SPLIT)
         CHK(copy_vec(e, s, p + ".bias", {D}, &P.conv_b[j]));
     }
     // transformer
@@ -363,10 +366,10 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     pr.end(s);
     const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);
-    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start));
+    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
     pr.end(s);
     pr.begin(PC_CONV, s, conv_fl);
-    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start));
+    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
@@ -447,11 +450,11 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     pr.end(s);
     const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);   // unett.py:99-100: conv_pos_embed is called WITHOUT a mask
-    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, nullptr, B));
+    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, nullptr, B, nullptr, conv_split(e)));
     pr.end(s);
     pr.begin(PC_CONV, s, conv_fl);
     float* emb = w.skips;  // free until the layer loop pushes the first skip; conv input and output must not alias
-    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, emb, Bp, N, D, nullptr, B));
+    HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, emb, Bp, N, D, nullptr, B, nullptr, conv_split(e)));
     pr.end(s);
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL(unett_assemble_kernel, dim3(ew_blocks((long)rows * D / 4)), dim3(256), 0, s, emb, temb, temb_stride, w.x,

@@ -178,7 +178,9 @@ static int convpos_impl(const float* x, const float* w, const float* bias, const
     }
     hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(ew_blocks((long)D * Kp)), dim3(256), 0, s, w, wp.p, (long)D, cpg, 31, Kp);
     KCHK();
-    HIPCHK(launch_convpos<T>(s, x, wp.p, Kp, bias, res, y, Bp, N, D, lens_host ? ld.p : nullptr, Bp));
+    const bool split = g_split16 && std::is_same_v<T, float> && convpos_can_split(D);
+    if (split) HIPCHK(maybe_split<T>(s, wp.p, (size_t)D * Kp));
+    HIPCHK(launch_convpos<T>(s, x, wp.p, Kp, bias, res, y, Bp, N, D, lens_host ? ld.p : nullptr, Bp, nullptr, split));
     HIPCHK(hipStreamSynchronize(s));
     return F5_OK;
 }
@@ -188,7 +190,10 @@ extern "C" int f5k_convpos(int32_t prec, const float* x, const float* w, const f
     if (!x || !w || !bias || !y || Bp <= 0 || N <= 0) return fail(F5_EINVAL, "f5k_convpos: bad arguments");
     if (D != 256 && D != 512 && D != 768 && D != 1024) return fail(F5_EINVAL, "f5k_convpos: D must be 256, 512, 768 or 1024");
     hipStream_t s = (hipStream_t)stream;
-    return F5K_BY_PREC(prec, convpos_impl, x, w, bias, res, lens_host, y, Bp, N, D, s);
+    g_split16 = prec == F5_PREC_F16X3;
+    const int rc = F5K_BY_PREC(prec, convpos_impl, x, w, bias, res, lens_host, y, Bp, N, D, s);
+    g_split16 = false;
+    return rc;
 }
 
 extern "C" int f5k_layernorm_mod(const float* x, const float* scale, const float* shift, float* out, int32_t R, int32_t D,
