@@ -59,8 +59,16 @@ __device__ __forceinline__ float bv_sin(float x) {
     return (q & 2) ? -res : res;
 }
 
-__device__ __forceinline__ float bv_snake(float v, float a, float invb) {
-    const float s = bv_sin(v * a);
+// precision "f16x3": the same reduction to [-pi, pi] by one multiple of 2 pi, then the hardware v_sin_f32 (argument in revolutions):
+// 9 issue slots instead of ~20; max |error| 3.5e-7 over the reduced range (tools/probe/sin_probe.hip) against 9.2e-8.
+__device__ __forceinline__ float bv_sin_hw(float x) {
+    const float k = rintf(x * 0.15915494309189535f);
+    float r = fmaf(-k, 6.283185482025146484375f, x);
+    r = fmaf(-k, -1.7484555314695172e-7f, r);
+    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+}
+template <bool HW> __device__ __forceinline__ float bv_snake(float v, float a, float invb) {
+    const float s = HW ? bv_sin_hw(v * a) : bv_sin(v * a);
     return v + invb * (s * s);
 }
 
@@ -74,12 +82,13 @@ constexpr int BV_TT = 8;
 
 struct BvSnake { float a0, a1, a2, a3, b0, b1, b2, b3; };
 
-__device__ __forceinline__ float4 bv_snake4(const float4 u, const BvSnake& p) {
-    return make_float4(bv_snake(2.0f * u.x, p.a0, p.b0), bv_snake(2.0f * u.y, p.a1, p.b1), bv_snake(2.0f * u.z, p.a2, p.b2),
-                       bv_snake(2.0f * u.w, p.a3, p.b3));
+template <bool HW> __device__ __forceinline__ float4 bv_snake4(const float4 u, const BvSnake& p) {
+    return make_float4(bv_snake<HW>(2.0f * u.x, p.a0, p.b0), bv_snake<HW>(2.0f * u.y, p.a1, p.b1), bv_snake<HW>(2.0f * u.z, p.a2, p.b2),
+                       bv_snake<HW>(2.0f * u.w, p.a3, p.b3));
 }
 
 // a[clamp(u)] from global rows (tile start and sequence edges)
+template <bool HW>
 __device__ __forceinline__ float4 bv_up_generic(const float* __restrict__ x, long u, long L, int C, int c, const float* sfu,
                                                 const BvSnake& p) {
     u = u < 0 ? 0 : (u > 2 * L - 1 ? 2 * L - 1 : u);
@@ -91,9 +100,10 @@ __device__ __forceinline__ float4 bv_up_generic(const float* __restrict__ x, lon
         const float4 v = *reinterpret_cast<const float4*>(x + tt * C + c);
         s.x += f * v.x; s.y += f * v.y; s.z += f * v.z; s.w += f * v.w;
     }
-    return bv_snake4(s, p);
+    return bv_snake4<HW>(s, p);
 }
 
+template <bool HW>
 static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restrict__ x, float* __restrict__ y, long L, int C,
                                                              const float* __restrict__ log_alpha, const float* __restrict__ log_beta,
                                                              const float* __restrict__ fu, const float* __restrict__ fd, int planar) {
@@ -116,7 +126,7 @@ static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restr
         };
         float4 a[12], r[6];
 #pragma unroll
-        for (int m = 0; m < 10; ++m) a[m] = bv_up_generic(x, 2 * t0 + m - 5, L, C, c, sfu, p);
+        for (int m = 0; m < 10; ++m) a[m] = bv_up_generic<HW>(x, 2 * t0 + m - 5, L, C, c, sfu, p);
 #pragma unroll
         for (int q = 0; q < 6; ++q) r[q] = row(t0 + q);
 #pragma unroll 1
@@ -134,8 +144,8 @@ static __global__ __launch_bounds__(256) void bv_act_kernel(const float* __restr
                     s1.x += f1 * v.x; s1.y += f1 * v.y; s1.z += f1 * v.z; s1.w += f1 * v.w;
                 }
                 // past the end a[u] repeats a[2L-1] (replicate padding of the low-pass filter)
-                a[10] = 2 * t + 5 <= 2 * L - 1 ? bv_snake4(s0, p) : a[9];
-                a[11] = 2 * t + 6 <= 2 * L - 1 ? bv_snake4(s1, p) : a[10];
+                a[10] = 2 * t + 5 <= 2 * L - 1 ? bv_snake4<HW>(s0, p) : a[9];
+                a[11] = 2 * t + 6 <= 2 * L - 1 ? bv_snake4<HW>(s1, p) : a[10];
                 float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
                 for (int m = 0; m < 12; ++m) {
@@ -532,6 +542,13 @@ extern "C" int f5_bigvgan_finalize(f5_bigvgan* v, f5_stream stream) {
 }
 
 // mel f32 addressed as mel[b * sb + c * sc + t * st] (element strides) -> wav f32[B, T * prod(rates)]
+// (precision f16x3 takes the hardware-sin activation)
+#define BV_ACT_LAUNCH(...)                                                                          \
+    do {                                                                                            \
+        if (v->cfg.precision == F5_PREC_F16X3) hipLaunchKernelGGL(bv_act_kernel<true>, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(bv_act_kernel<false>, __VA_ARGS__);                                  \
+    } while (0)
+
 extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, int32_t T, int64_t sb, int64_t sc, int64_t st,
                                   float* wav, f5_stream stream) {
     if (!v || !mel || !wav) return fail(F5_EINVAL, "f5_bigvgan_forward: null argument");
@@ -628,11 +645,11 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
                     const bool use_narrow1 = narrow_ok && rb.c1[m].wn && conv_narrow_ok(ch, rb.k, d);
                     const bool use_narrow2 = narrow_ok && rb.c2[m].wn && conv_narrow_ok(ch, rb.k, 1);
                     const int planar1 = implicit && !use_narrow1 && rb.c1[m].split, planar2 = implicit && !use_narrow2 && rb.c2[m].split;
-                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rin, acti, L, ch, rb.act[2 * m].alpha,
+                    BV_ACT_LAUNCH(dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, rin, acti, L, ch, rb.act[2 * m].alpha,
                                        rb.act[2 * m].beta, v->fu, v->fd, planar1);
                     KCHK();
                     HIPCHK(conv(rb.c1[m], rb.k, d, EpiStore<float>{t1, ch, rb.c1[m].b, F5_ACT_NONE}));
-                    hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, t1, acti, L, ch, rb.act[2 * m + 1].alpha,
+                    BV_ACT_LAUNCH(dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, t1, acti, L, ch, rb.act[2 * m + 1].alpha,
                                        rb.act[2 * m + 1].beta, v->fu, v->fd, planar2);
                     KCHK();
                     // x_j = x_j + (conv2(.) + bias): residual epilogue (in place from the second pair on)
@@ -642,7 +659,7 @@ extern "C" int f5_bigvgan_forward(f5_bigvgan* v, const float* mel, int32_t B, in
             hipLaunchKernelGGL(bv_mean_kernel, dim3(ew_blocks(cnt / 4)), dim3(256), 0, s, r, (long)lc_max, c.num_kernels, x, cnt / 4);
             KCHK();
         }
-        hipLaunchKernelGGL(bv_act_kernel, dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
+        BV_ACT_LAUNCH(dim3(ew_blocks((L + BV_TT - 1) / BV_TT * (ch / 4))), dim3(256), 0, s, x, act, L, ch, v->post_act.alpha, v->post_act.beta,
                            v->fu, v->fd, 0);
         hipLaunchKernelGGL(bv_post_kernel, dim3(ew_blocks(L)), dim3(256), 0, s, act, v->post_w, v->post_b, wav + (size_t)b * Lout, L, ch,
                            c.use_tanh_at_final);
