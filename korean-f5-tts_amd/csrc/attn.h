@@ -461,7 +461,7 @@ inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const fl
                                          int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
                                          const int* o_row_start = nullptr, int o_planar = 0) {
     // 128 query rows per workgroup as 8 waves x 16 rows: two waves per SIMD (one's softmax / split arithmetic overlaps the other's
-    // MFMAs) sharing one staged K / V tile.  (4 waves x 32 rows: one wave per SIMD, every phase serial: 42 us at C2 against 3x us;
+    // MFMAs) sharing one staged K / V tile.  (4 waves x 32 rows: one wave per SIMD, every phase serial: 44 us at C2 against 39;
     // 4 waves x 16 rows: twice the staging per query, 47 us -- tools/probe/attn_probe.hip)
     constexpr int smem = 2 * 4 * 64 * (128 + 16);
     static bool attr_set = false;
