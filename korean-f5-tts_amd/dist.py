@@ -17,28 +17,102 @@ def utterance_cost(n_frames: int) -> float:
     return 16.0 * n_frames * 1024 + 4.0 * n_frames * n_frames
 
 
-def partition(durations: list[int], world: int) -> list[list[int]]:
-    """Greedy longest-processing-time partition of utterance indices into `world` shards of balanced cost.
-    Deterministic, so every rank derives the same assignment (no metadata exchange needed)."""
-    order = sorted(range(len(durations)), key=lambda i: (-durations[i], i))
-    loads = [0.0] * world
-    shards: list[list[int]] = [[] for _ in range(world)]
-    for i in order:
-        r = min(range(world), key=lambda k: (loads[k], len(shards[k]), k))
-        shards[r].append(i)
-        loads[r] += utterance_cost(durations[i])
-    return shards
+# One backbone call works on at most 32,768 rows (csrc/engine.hip::chunk_utts: the activations of a chunk stay inside the
+# Infinity Cache) = 16,384 frames with CFG: a batch larger than that is stepped chunk by chunk anyway, so a bigger batch
+# buys nothing and only pads more rows to its longest member.
+MAX_BATCH_FRAMES = 16384
 
 
-def batches_of(shard: list[int], durations: list[int], batch_size: int) -> list[list[int]]:
-    """Length-sorted batches of at most `batch_size` utterances (padding waste is smallest between neighbours)."""
+def batches_of(shard: list[int], durations: list[int], batch_size: int, max_batch_frames: int = MAX_BATCH_FRAMES) -> list[list[int]]:
+    """Length-sorted batches of a shard under a FRAME budget, the reference's batching rule (utils_eval.py:146-202:
+    `infer_batch_size` counts mel frames, not utterances): a batch takes neighbours of the sorted list while
+    count x (its longest member) <= max_batch_frames and count <= batch_size.  A short last batch is evened out with
+    its predecessor (a handful of rows runs the GEMMs far below their many-row rate)."""
     s = sorted(shard, key=lambda i: (-durations[i], i))
-    return [s[k:k + batch_size] for k in range(0, len(s), batch_size)]
+    out: list[list[int]] = []
+    k = 0
+    while k < len(s):
+        cap = max(1, min(batch_size, max_batch_frames // max(durations[s[k]], 1)))
+        out.append(s[k:k + cap])
+        k += cap
+    if len(out) >= 2 and 2 * len(out[-1]) < len(out[-2]):
+        both = out[-2] + out[-1]
+        h = (len(both) + 1) // 2
+        out[-2:] = [both[:h], both[h:]]
+    return out
+
+
+def padded_cost(shard: list[int], durations: list[int], batch_size: int, max_batch_frames: int = MAX_BATCH_FRAMES) -> float:
+    """Cost of a shard AS IT RUNS: every batch is padded to its longest member, and with the default
+    attn_mask_enabled=False the pad rows are computed like any other (modules.py:499-508: no key mask)."""
+    return sum(len(b) * utterance_cost(durations[b[0]]) for b in batches_of(shard, durations, batch_size, max_batch_frames))
+
+
+def partition(durations: list[int], world: int, batch_size: int = 32, max_batch_frames: int = MAX_BATCH_FRAMES) -> list[list[int]]:
+    """Shards of utterance indices, one per rank: CONTIGUOUS slices of the length-sorted list (so that a rank's batches
+    are length-homogeneous: the reference buckets by length for the same reason, utils_eval.py:146-202) cut so that the
+    largest PADDED cost of a rank is minimal (binary search on the bound + greedy longest feasible slice; shard sizes
+    differ: the rank with the longest utterances gets fewer of them).  Deterministic, so every rank derives the same
+    assignment and no metadata is exchanged.  Ranks past the number of utterances get empty shards."""
+    order = sorted(range(len(durations)), key=lambda i: (-durations[i], i))
+    n = len(order)
+    if n == 0:
+        return [[] for _ in range(world)]
+    valid = [utterance_cost(durations[i]) for i in order]
+
+    def cut(bound: float) -> list[list[int]]:
+        slices, i = [], 0
+        while i < n:
+            best, v = i + 1, 0.0
+            for j in range(i, n):
+                v += valid[j]                       # valid cost <= padded cost: nothing longer can fit once it is over
+                if v > bound and j > i:
+                    break
+                if padded_cost(order[i:j + 1], durations, batch_size, max_batch_frames) <= bound:
+                    best = j + 1
+            slices.append(order[i:best])
+            i = best
+        return slices
+
+    lo, hi = max(valid), n * max(valid)          # hi: everything in one shard, padded to the longest
+    for _ in range(32):
+        mid = 0.5 * (lo + hi)
+        if len(cut(mid)) <= world:
+            hi = mid
+        else:
+            lo = mid
+    shards = cut(hi)
+    return shards + [[] for _ in range(world - len(shards))]
+
+
+@torch.no_grad()
+def run_shard(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durations: list[int], shard: list[int], *,
+              per_rank: int, batch_size: int = 32, max_batch_frames: int = MAX_BATCH_FRAMES, device=None, **sample_kw) -> torch.Tensor:
+    """One rank's part of the job: its shard (already in length-sorted order) batch by batch through model.sample().
+    Returns f32[per_rank, N_max, mel]: slot k = the shard's k-th utterance, zero past its own length."""
+    n_max = max(durations)
+    mel_dim = conds[0].shape[-1]
+    device = device if device is not None else getattr(model, "device", conds[0].device)
+    local = torch.zeros(per_rank, n_max, mel_dim, device=device, dtype=torch.float32)
+    k0 = 0
+    for batch in batches_of(shard, durations, batch_size, max_batch_frames):
+        assert batch == shard[k0:k0 + len(batch)], "shards are slices of the length-sorted list"
+        ref_lens = [conds[u].shape[0] for u in batch]
+        cond = torch.nn.utils.rnn.pad_sequence([conds[u] for u in batch], batch_first=True)
+        text = torch.nn.utils.rnn.pad_sequence([texts[u] for u in batch], batch_first=True, padding_value=-1)
+        dur = torch.tensor([durations[u] for u in batch], dtype=torch.long)
+        out, _ = model.sample(cond, text, dur, lens=torch.tensor(ref_lens, dtype=torch.long), **sample_kw)
+        # the batch's rows are consecutive slots: one masked store (frames past an utterance's own length are zeroed)
+        nb = out.shape[1]
+        valid = (torch.arange(nb)[None, :] < dur[:, None]).to(device=device, dtype=local.dtype, non_blocking=True)
+        torch.mul(out.to(local.dtype), valid[..., None], out=local[k0:k0 + len(batch), :nb])
+        k0 += len(batch)
+    return local
 
 
 @torch.no_grad()
 def dp_sample(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durations: list[int], *, batch_size: int = 32,
-              group=None, device=None, collective_on_host: bool = False, **sample_kw):
+              max_batch_frames: int = MAX_BATCH_FRAMES, group=None, device=None, collective_on_host: bool = False, **sample_kw):
     """Synthesises every utterance of the job on its owner rank and returns ALL mels on every rank.
 
     conds[i]: f32[ref_i, mel] prompt mel; texts[i]: i64[nt_i]; durations[i]: total frames.
@@ -52,25 +126,13 @@ def dp_sample(model, conds: list[torch.Tensor], texts: list[torch.Tensor], durat
     configure_host_threads(int(os.environ.get("F5_HOST_THREADS", "1")))   # one rank per GPU shares the host: see utils.py
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    shards = partition(durations, world)
-    mine = shards[rank]
+    shards = partition(durations, world, batch_size, max_batch_frames)
     n_max = max(durations)
-    per_rank = max(len(s) for s in shards)
+    per_rank = max(len(s) for s in shards)            # shard sizes differ (equal COST, not equal count): slots are padded
     mel_dim = conds[0].shape[-1]
     device = device if device is not None else getattr(model, "device", conds[0].device)
-    local = torch.zeros(per_rank, n_max, mel_dim, device=device, dtype=torch.float32)
-    slot = {u: k for k, u in enumerate(mine)}
-    for batch in batches_of(mine, durations, batch_size):
-        ref_lens = [conds[u].shape[0] for u in batch]
-        cond = torch.nn.utils.rnn.pad_sequence([conds[u] for u in batch], batch_first=True)
-        text = torch.nn.utils.rnn.pad_sequence([texts[u] for u in batch], batch_first=True, padding_value=-1)
-        dur = torch.tensor([durations[u] for u in batch], dtype=torch.long)
-        out, _ = model.sample(cond, text, dur, lens=torch.tensor(ref_lens, dtype=torch.long), **sample_kw)
-        # the batch's rows go to their slots in ONE masked scatter (frames past an utterance's own length are zeroed)
-        nb = out.shape[1]
-        valid = (torch.arange(nb)[None, :] < dur[:, None]).to(device=device, dtype=local.dtype, non_blocking=True)
-        idx = torch.tensor([slot[u] for u in batch], dtype=torch.long).to(device, non_blocking=True)
-        local[:, :nb].index_copy_(0, idx, out.to(local.dtype) * valid[..., None])
+    local = run_shard(model, conds, texts, durations, shards[rank], per_rank=per_rank, batch_size=batch_size,
+                      max_batch_frames=max_batch_frames, device=device, **sample_kw)
     if world == 1:
         gathered = local.unsqueeze(0)
     else:

@@ -82,15 +82,72 @@ def test_dp_sample_world2_gloo_single_all_gather():
     assert all(r[2] == 1 for r in res), "exactly one collective on the data path"
 
 
-def test_partition_is_balanced_and_complete():
+def _c4_durations():
     g = torch.Generator().manual_seed(1234)
-    durs = [int(x) for x in torch.randint(384, 1025, (256,), generator=g)]  # BASELINE config C4 lengths
-    shards = D.partition(durs, 8)
-    assert sorted(i for s in shards for i in s) == list(range(256))
-    assert all(len(s) == 32 for s in shards)
-    loads = [sum(D.utterance_cost(durs[i]) for i in s) for s in shards]
-    assert max(loads) / min(loads) < 1.01
-    assert D.partition(durs, 8) == shards  # deterministic: every rank derives the same assignment
+    return [1024] + [int(x) for x in torch.randint(384, 1025, (255,), generator=g)]   # bench.py::make_c4_job (BASELINE C4)
+
+
+def test_partition_is_complete_contiguous_and_deterministic():
+    durs = _c4_durations()
+    order = sorted(range(256), key=lambda i: (-durs[i], i))
+    for world in (1, 2, 3, 4, 8):
+        shards = D.partition(durs, world)
+        assert len(shards) == world
+        assert [i for s in shards for i in s] == order          # contiguous slices of the length-sorted list, nothing lost
+        assert D.partition(durs, world) == shards               # every rank derives the same assignment
+        for s in shards:                                        # a rank's batches are consecutive runs of its shard
+            assert [i for b in D.batches_of(s, durs, 32) for i in b] == s
+            for b in D.batches_of(s, durs, 32):
+                assert len(b) <= 32 and (len(b) == 1 or len(b) * durs[b[0]] <= D.MAX_BATCH_FRAMES)
+
+
+def test_partition_padded_cost_is_balanced():
+    """What a rank pays is the PADDED cost of its batches (attn_mask_enabled=False computes pad rows): the slowest rank
+    must stay within 10 % of an ideal split of the valid work (round 2's LPT deal: 1.51 at world 8)."""
+    durs = _c4_durations()
+    total_valid = sum(D.utterance_cost(d) for d in durs)
+    for world in (1, 2, 4, 8):
+        shards = D.partition(durs, world)
+        worst = max(D.padded_cost(s, durs, 32) for s in shards)
+        assert worst <= 1.10 * total_valid / world, (world, worst / (total_valid / world))
+        # per batch: padded frames / valid frames
+        for s in shards:
+            for b in D.batches_of(s, durs, 32):
+                assert len(b) * durs[b[0]] <= 1.12 * sum(durs[i] for i in b)
+
+
+def test_partition_edge_cases():
+    assert D.partition([], 4) == [[], [], [], []]
+    assert D.partition([50, 70], 4) == [[1], [0], [], []]                    # more ranks than utterances: empty shards
+    assert D.partition([100] * 7, 2) in ([[0, 1, 2, 3], [4, 5, 6]], [[0, 1, 2], [3, 4, 5, 6]])
+    one = D.partition([30, 20, 90, 40], 1)
+    assert one == [[2, 3, 0, 1]]
+    assert D.batches_of([2, 3, 0, 1], [30, 20, 90, 40], batch_size=3, max_batch_frames=100) == [[2], [3, 0], [1]]
+    # frame budget: a batch never exceeds max_batch_frames padded frames unless it is a single utterance
+    bs = D.batches_of(list(range(6)), [60, 60, 60, 60, 60, 60], batch_size=32, max_batch_frames=130)
+    assert [len(b) for b in bs] == [2, 2, 2]
+
+
+def _worker_sparse(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conds, texts, durs = make_job(2)                          # 2 utterances on 3 ranks: rank 2's shard is empty
+    mels, _ = D.dp_sample(FakeModel(), conds, texts, durs, batch_size=3, device="cpu")
+    q.put((rank, bool(torch.allclose(mels, expected(conds, texts, durs))), 1))
+    dist.destroy_process_group()
+
+
+def test_dp_sample_world3_with_an_empty_shard():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
 
 
 def test_world1_no_collective():

@@ -26,6 +26,10 @@ for st in "$@"; do
     bench) run bench 600 python bench.py --steps 5 --warmup 2 ;;
     bench_nocpu) run bench_nocpu 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     prof) run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 ;;
+    dist) run dist 600 python -m pytest tests/test_dist_gpu.py -q -m gpu -s --timeout 300 ;;
+    pmc_c2) run pmc_c2 1000 tools/pmc_pass.sh c2 gpurun_out/pmc_c2 ;;
+    pmc_c3) run pmc_c3 1000 tools/pmc_pass.sh c3chunk gpurun_out/pmc_c3chunk ;;
+    selflaunch) run selflaunch 400 python bench.py --gpus 2 --steps 3 --warmup 1 --rehearse-one-gpu --no-cpu-baseline --c4-utts 64 ;;
     *) echo "unknown stage $st"; exit 2 ;;
   esac
 done
