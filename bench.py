@@ -44,7 +44,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x3": 2500.0 / 3}   # (f16x3: three f16 MFMAs per product)  # dense, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def parse():

@@ -210,8 +210,15 @@ def cross_fade_concat(waves: list[np.ndarray], cross_fade_duration_: float = cro
 def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
                         progress=None, target_rms=target_rms, cross_fade_duration=cross_fade_duration,
                         nfe_step=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
-                        speed=speed, fix_duration=fix_duration, device=None, seed=None, text_tokenizer=None):
-    """Returns (final_wave f32 numpy, sample_rate, combined mel [100, T_total]) like the non-streaming branch.
+                        speed=speed, fix_duration=fix_duration, device=None, streaming=False, chunk_size=2048, seed=None,
+                        text_tokenizer=None):
+    """A GENERATOR, as in the reference (utils_infer.py:504-522,711-778):
+      streaming=False  yields ONE item (final_wave f32 numpy, sample_rate, combined mel [100, T_total]) -- the cross-faded
+                       concatenation over the text batches; (None, sample_rate, None) when there is no batch
+                       (`infer_process` returns `next(...)` of it);
+      streaming=True   yields (wave[j : j + chunk_size], sample_rate) per chunk of every batch's waveform in turn, no cross-fade
+                       (the socket server's mode, socket_server.py:138-177).
+    `progress`: None or an object with `.tqdm(iterable)` (the reference passes the tqdm module).
 
     Text front-end: the reference turns `ref_text + gen_text` into tokens per `model_obj._tokenizer_type` -- for the kor_*
     types through Korean G2P / jamo decomposition / allophone rules (utils_infer.py:549-660: g2pk and the repo's own rule
@@ -225,8 +232,9 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     if text_tokenizer is None and isinstance(tok_type, str) and tok_type.startswith("kor_"):
         raise NotImplementedError(f"model tokenizer type {tok_type!r}: pass text_tokenizer= (str -> list[str], the reference's "
                                   "utils_infer.py:549-660 conversion) -- the Korean G2P / allophone front-end is not part of this engine")
-    waves, specs = [], []
-    for gen_text in gen_text_batches:
+
+    def process_batch(gen_text):
+        """One text batch -> (wave f32 numpy [nw], generated mel numpy [100, T])   (utils_infer.py:541-709)."""
         a, rms, rtext, ref_len, duration = prompt_numerics(audio, sr, ref_text, gen_text, speed, fix_duration, target_rms)
         a = a.to(device)
         text_list = [text_tokenizer(rtext + gen_text)] if text_tokenizer is not None else [rtext + gen_text]
@@ -245,15 +253,28 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
             wave = vocoder.decode(generated) if mel_spec_type == "vocos" else vocoder(generated)   # utils_infer.py:702-705
             if rms < target_rms:
                 wave = wave * rms / target_rms
-            waves.append(wave.squeeze().cpu().numpy())
-            specs.append(generated[0].cpu().numpy())
+            return wave.squeeze().cpu().numpy(), generated[0].cpu().numpy()
+
+    batches = progress.tqdm(gen_text_batches) if progress is not None and hasattr(progress, "tqdm") else gen_text_batches
+    if streaming:
+        for gen_text in batches:
+            wave, _spec = process_batch(gen_text)
+            for j in range(0, len(wave), chunk_size):
+                yield wave[j:j + chunk_size], target_sample_rate
+        return
+    waves, specs = [], []
+    for gen_text in batches:
+        wave, spec = process_batch(gen_text)
+        waves.append(wave)
+        specs.append(spec)
     if not waves:
-        return None, target_sample_rate, None
-    return cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
+        yield None, target_sample_rate, None
+        return
+    yield cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
 
 
-def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_type=mel_spec_type, target_rms=target_rms,
-                  cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
+def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_type=mel_spec_type, show_info=print, progress=None,
+                  target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
                   sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, seed=None,
                   text_tokenizer=None):
     """ref_audio = (tensor [channels, nw], sample_rate) instead of a path (no torchaudio.load here); otherwise
@@ -261,7 +282,10 @@ def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_ty
     audio, sr = ref_audio
     max_chars = int(len(ref_text.encode("utf-8")) / (audio.shape[-1] / sr) * (22 - audio.shape[-1] / sr) * speed)
     batches = chunk_text(gen_text, max_chars=max_chars)
-    return infer_batch_process((audio, sr), ref_text, batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
-                               target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
-                               cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed,
-                               fix_duration=fix_duration, device=device, seed=seed, text_tokenizer=text_tokenizer)
+    if show_info is not None:
+        show_info(f"Generating audio in {len(batches)} batches...")
+    return next(infer_batch_process((audio, sr), ref_text, batches, model_obj, vocoder, mel_spec_type=mel_spec_type,
+                                    progress=progress, target_rms=target_rms, cross_fade_duration=cross_fade_duration,
+                                    nfe_step=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef,
+                                    speed=speed, fix_duration=fix_duration, device=device, seed=seed,
+                                    text_tokenizer=text_tokenizer))

@@ -29,7 +29,8 @@ KW = dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)
 def make_job(n=12, seed=11):
     g = torch.Generator().manual_seed(seed)
     durs = [int(x) for x in torch.randint(40, 131, (n,), generator=g)]
-    durs[3] = durs[7]                                   # a tie in the sort key
+    if n > 7:
+        durs[3] = durs[7]                               # a tie in the sort key
     conds = [torch.randn(d // 4, 100, generator=g) for d in durs]
     texts = [torch.randint(1, NV - 1, (max(2, round(0.15 * d)),), generator=g) for d in durs]
     return conds, texts, durs

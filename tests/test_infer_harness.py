@@ -100,8 +100,8 @@ def test_infer_batch_process_matches_reference_harness():
         m_ref._tokenizer_type = "custom"
         wave_r, sr_r, spec_r = next(ui.infer_batch_process((audio, 24000), "ref text here.", TEXTS, m_ref, FakeVocoder(),
                                                            progress=None, device="cpu", **kw))
-        wave_m, sr_m, spec_m = I.infer_batch_process((audio, 24000), "ref text here.", TEXTS, m_mine, FakeVocoder(),
-                                                      device="cpu", **kw)
+        wave_m, sr_m, spec_m = next(I.infer_batch_process((audio, 24000), "ref text here.", TEXTS, m_mine, FakeVocoder(),
+                                                           device="cpu", **kw))
         assert sr_r == sr_m == 24000
         assert len(m_ref.calls) == len(m_mine.calls) == 2
         for cr, cm in zip(m_ref.calls, m_mine.calls):
@@ -111,6 +111,26 @@ def test_infer_batch_process_matches_reference_harness():
             # same characters reach the model
             assert "".join(cr["text"][0]) == "".join(cm["text"][0]).replace(";", ",")
         assert np.allclose(wave_r, wave_m, atol=1e-7) and np.array_equal(spec_r, spec_m)
+        # the streaming branch (utils_infer.py:711-714,725-728: chunks of every batch's waveform in turn, no cross-fade)
+        for chunk_size in (64, 37):
+            m_ref, m_mine = FakeModel(), FakeModel()
+            m_ref._tokenizer_type = "custom"
+            ch_r = list(ui.infer_batch_process((audio, 24000), "ref text here.", TEXTS, m_ref, FakeVocoder(), progress=None,
+                                               device="cpu", streaming=True, chunk_size=chunk_size, **kw))
+            ch_m = list(I.infer_batch_process((audio, 24000), "ref text here.", TEXTS, m_mine, FakeVocoder(), device="cpu",
+                                              streaming=True, chunk_size=chunk_size, **kw))
+            assert len(ch_r) == len(ch_m) > 2
+            for (wr, sr_r), (wm, sr_m) in zip(ch_r, ch_m):
+                assert sr_r == sr_m == 24000 and wr.shape == wm.shape and len(wm) <= chunk_size
+                assert np.allclose(wr, wm, atol=1e-7)
+    # no batches: one (None, sr, None) item in both
+    assert next(ui.infer_batch_process((audio, 24000), "ref text here.", [], FakeModel(), FakeVocoder(), progress=None,
+                                       device="cpu")) == (None, 24000, None)
+    assert next(I.infer_batch_process((audio, 24000), "ref text here.", [], FakeModel(), FakeVocoder(), device="cpu")) == (None, 24000, None)
+    import tqdm
+    w_t, _, _ = next(I.infer_batch_process((audio, 24000), "ref text here.", TEXTS, FakeModel(), FakeVocoder(), device="cpu",
+                                           progress=tqdm, **kw))
+    assert np.allclose(w_t, wave_m, atol=0)
 
 
 def test_korean_tokenizer_types_need_an_explicit_tokenizer():
@@ -120,9 +140,9 @@ def test_korean_tokenizer_types_need_an_explicit_tokenizer():
     m = FakeModel()
     m._tokenizer_type = "kor_allophone"
     with pytest.raises(NotImplementedError, match="text_tokenizer"):
-        I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu")
-    I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu",
-                          text_tokenizer=lambda s: ["<" + c + ">" for c in s])
+        next(I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu"))
+    next(I.infer_batch_process((audio, 24000), "ref text.", ["some text to say."], m, FakeVocoder(), device="cpu",
+                               text_tokenizer=lambda s: ["<" + c + ">" for c in s]))
     assert m.calls and m.calls[0]["text"][0][0] == "<r>" and isinstance(m.calls[0]["text"][0], list)
 
 

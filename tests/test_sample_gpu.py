@@ -331,7 +331,7 @@ def test_infer_process_end_to_end_vs_oracle():
     audio = torch.randn(1, 9000, generator=g) * 0.05
     ref_text, gen_text = "hello there.", "General Kenobi, you are a bold one."
     kw = dict(nfe_step=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
-    wave, sr, spec = I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw)
+    wave, sr, spec = next(I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw))
     # oracle pipeline
     a, rms, rtext, ref_len, dur = I.prompt_numerics(audio, 24000, ref_text, gen_text)
     cond = O.mel_spectrogram_vocos(a).permute(0, 2, 1)
@@ -380,7 +380,7 @@ def test_real_speech_prompt_mel_and_harness():
     voc.load_state_dict(vsd)
     voc.to(DEV)
     kw = dict(nfe_step=5, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
-    wave_out, sr, spec = I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw)
+    wave_out, sr, spec = next(I.infer_batch_process((audio, 24000), ref_text, [gen_text], model, voc, **kw))
     a, rms, rtext, ref_len, dur = I.prompt_numerics(audio, 24000, ref_text, gen_text)
     cond = O.mel_spectrogram_vocos(a).permute(0, 2, 1)
     text = P.utils.list_str_to_tensor([rtext + gen_text])

@@ -11,11 +11,64 @@ import sys
 wl, out = sys.argv[1], sys.argv[2]
 
 
+def _targs(s, i):
+    """template-argument list of an Itanium-mangled name, for the subset this library uses (c++filt of this image does not know
+    DF16b): returns (list of strings, index after the closing E)"""
+    out = []
+    while i < len(s) and s[i] != "E":
+        if s.startswith("DF16b", i):
+            out.append("bf16"); i += 5
+        elif s.startswith("DF16_", i):
+            out.append("f16"); i += 5
+        elif s[i] == "f":
+            out.append("float"); i += 1
+        elif s[i] == "L":                      # literal: L<type><value>E
+            j = s.index("E", i)
+            out.append(s[i + 2:j].replace("n", "-")); i = j + 1
+        elif s.startswith("NS_", i) or s[i].isdigit():
+            nested = s.startswith("NS_", i)    # N S_ <name> [I <args> E] E : a name inside namespace f5
+            if nested:
+                i += 3
+            m = re.match(r"\d+", s[i:])
+            n = int(m.group()); i += len(m.group())
+            name = s[i:i + n]; i += n
+            if i < len(s) and s[i] == "I":
+                sub, i = _targs(s, i + 1)
+                name += "<" + ", ".join(sub) + ">"
+            if nested:
+                i += 1                         # the E that closes the nested name
+            out.append(name)
+        else:
+            break
+    return out, i + 1
+
+
+def demangle(k):
+    """rocprofv3 leaves some kernel names mangled in the counter CSVs"""
+    m = re.match(r"_ZN2f5(\d+)", k)
+    if not m:
+        return k
+    n = int(m.group(1))
+    i = m.end()
+    name = k[i:i + n]
+    i += n
+    if i < len(k) and k[i] == "I":
+        try:
+            args, _ = _targs(k, i + 1)
+            return "f5::" + name + "<" + ", ".join(args) + ">"
+        except Exception:
+            return "f5::" + name
+    return "f5::" + name
+
+
 def short(k):
+    k = demangle(k)
     for a, b in (("f5::", ""), ("gemm_tn_glds_kernel", "G2"), ("gemm_tn_kernel", "G1"), ("gemm_pp_kernel", "G3"), ("(anonymous namespace)::", "")):
         k = k.replace(a, b)
+    k = re.sub(r"^void ", "", k)
     k = re.sub(r"\(.*$", "", k)
-    return re.sub(r"^void ", "", k)[:100]
+    k = k.replace("__hip_bfloat16", "bf16").replace("_Float16", "f16")
+    return k[:110]
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
