@@ -39,6 +39,12 @@ extern "C" {
                             halves (hi + lo, 22 bits) and the product takes three fp16 MFMAs: f32-level results; the backbone GEMMs run
                             at ~2.5-3x the f32 MFMA rate, a C2 utterance in 0.46x the f32 time.  |activation| < 65504 as for F5_PREC_F16 */
 
+#define F5_PREC_F16P 4   /* F5_PREC_F16 in the transformer blocks (fp16 MFMA operands, f32 accumulate / residual / norms) with the
+                            model's input and output layers -- input projection, conv position embedding, final norm + output
+                            projection -- as split-fp16 products on f32 operands (as F5_PREC_F16X3): the rounding of the ODE state
+                            entering and of the flow prediction leaving the backbone is what dominates F5_PREC_F16's error (DESIGN.md
+                            section 3, tools/x3_ablate.py); meets the 1e-3 parity bar at ~F5_PREC_F16 speed */
+
 #define F5_BACKBONE_DIT 0
 #define F5_BACKBONE_UNETT 1
 

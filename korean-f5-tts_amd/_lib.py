@@ -8,9 +8,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libf5hip.so")
 
-F5_PREC_F32, F5_PREC_BF16, F5_PREC_F16, F5_PREC_F16X3 = 0, 1, 2, 3
+F5_PREC_F32, F5_PREC_BF16, F5_PREC_F16, F5_PREC_F16X3, F5_PREC_F16P = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": F5_PREC_F32, "fp32": F5_PREC_F32, "bf16": F5_PREC_BF16, "f16": F5_PREC_F16, "fp16": F5_PREC_F16,
-              "f16x3": F5_PREC_F16X3}
+              "f16x3": F5_PREC_F16X3, "f16p": F5_PREC_F16P, "parity": F5_PREC_F16P}
 F5_BACKBONE_DIT, F5_BACKBONE_UNETT = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4
 PROFILE_CLASSES = ("gemm", "attention", "layernorm", "convpos", "misc", "text_encoder", "time_adaln")

@@ -15,7 +15,7 @@ from .engine import Engine
 class _HipBackbone(nn.Module):
     backbone_name = "DiT"
 
-    def __init__(self, *, mel_dim=100, text_num_embeds=256, precision="bf16", device=None, max_pos=8192, **arch):
+    def __init__(self, *, mel_dim=100, text_num_embeds=256, precision="f16p", device=None, max_pos=8192, **arch):
         super().__init__()
         arch.pop("dropout", None)
         arch.pop("attn_backend", None)          # one attention implementation: the gfx950 flash kernel

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libf5hip.so")
 OBJDIR = os.path.join(ROOT, "build", "f5hip")
-SOURCES = ["engine.hip", "engine_bf16.hip", "engine_f16.hip", "engine_f32.hip", "vocos.hip", "bigvgan.hip", "kapi.hip", "mel.hip"]
+SOURCES = ["engine.hip", "engine_bf16.hip", "engine_f16.hip", "engine_f32.hip", "vocos.hip", "bigvgan.hip", "kapi.hip", "kapi_diag.hip", "mel.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["../../include/f5_hip.h"]
 # -ffp-contract=off: a*b + c is evaluated as written in every kernel.  With the default (fast) hipcc fuses multiply-adds
 # where its instruction selection happens to see them, which differs between instantiations of one epilogue in different

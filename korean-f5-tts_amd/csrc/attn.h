@@ -24,6 +24,25 @@
 
 namespace f5 {
 
+// Workgroup -> (batch row x head, query block).  The grid is (Bp * H, query blocks) and workgroup ids (x fastest) are dealt
+// round-robin over the 8 XCDs, so with the plain mapping all query blocks of one head already meet in ONE XCD's L2 -- but a layer
+// of 512 different heads is dispatched between two query blocks of the same head: at C3's 32 x 16 heads every XCD streams 16 MB
+// of K / V per layer through its 4 MB L2 and each query block fetches its head's K / V again (rocprofv3 FETCH_SIZE at 32,768
+// rows: 1,141 MB per launch against 201 MB of q + k + v, 5.2 TB/s on the fabric).  Here the ids of one XCD walk the query blocks
+// of a head before the next head (8 heads x 8 blocks x 256 KB of K / V = 2 MB live per XCD).
+__device__ __forceinline__ void attn_block_map(int& bhid, int& qblk) {
+    const int nbh = gridDim.x, nqb = gridDim.y;
+    bhid = blockIdx.x;
+    qblk = blockIdx.y;
+    if ((nbh & 7) == 0) {
+        const int lin = blockIdx.y * nbh + blockIdx.x;
+        const int xcd = lin & 7, j = lin >> 3;
+        qblk = j % nqb;
+        bhid = (j / nqb) * 8 + xcd;
+    }
+}
+
+
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, const T* __restrict__ K,
                                                        const T* __restrict__ Vt, T* __restrict__ O, int H, int N,
@@ -33,7 +52,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
     // grid: x = (batch row, head), y = query block: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so with
     // heads on x the query blocks that share one head's K / V meet in ONE XCD's L2 (with query blocks on x every XCD
     // streamed every head's K / V: tools/probe/attn_probe.hip)
-    if (q_lens && (int)blockIdx.y * 128 >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;   // (block-uniform, before any barrier)
+    int bhid, qblk;
+    attn_block_map(bhid, qblk);
+    if (q_lens && qblk * 128 >= q_lens[(bhid / H) % nbatch_lens]) return;   // (block-uniform, before any barrier)
     constexpr int RB = 64 * sizeof(T);          // bytes per 64-element row (128 / 256)
     constexpr int RS = RB + 16;                 // padded LDS row stride
     constexpr int NF = RB / 64;                 // 16-byte fragments per lane per 64-element row (2 / 4)
@@ -45,9 +66,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ Q, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int h = bhid % H, b = bhid / H;
     const size_t bh = (size_t)b * H + h;
-    const int q0 = blockIdx.y * 128 + wave * 32;
+    const int q0 = qblk * 128 + wave * 32;
     int kv_len = N;
     if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
     const int nkt = (kv_len + 63) / 64;
@@ -243,14 +264,17 @@ __device__ __forceinline__ f32x4 mma_h(const u32x4& a, const u32x4& b, f32x4 c) 
 
 // DIAG (tools/attn_probe.hip only; 0 in the product): bit 0 = stage K / V without splitting, 1 = no softmax arithmetic,
 // 2 = no V^T P^T MFMAs, 3 = no K Q^T MFMAs, 4 = no global loads after the first tile -- the cost of each part by omission.
-template <int QS, int NW = 4, int DIAG = 0>
+// HI (diagnostic F5_X3_ABLATE, tools/x3_ablate.py): bit 0 = K Q^T with the hi x hi product only (plain f16), bit 1 = V^T P^T likewise.
+template <int QS, int NW = 4, int DIAG = 0, int HI = 0>
 static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ Vt, float* __restrict__ O, int H, int N,
                                                              int Npad, const int* __restrict__ kv_lens, int nbatch_lens,
                                                              const int* __restrict__ q_lens, const int* __restrict__ o_row_start,
                                                              int o_planar) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (q_lens && (int)blockIdx.y * (NW * 16 * QS) >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;   // (grid as attn_fwd_kernel)
+    int bhid, qblk;
+    attn_block_map(bhid, qblk);
+    if (q_lens && qblk * (NW * 16 * QS) >= q_lens[(bhid / H) % nbatch_lens]) return;   // (grid as attn_fwd_kernel)
     constexpr int RS = 128 + 16;                // f16 plane row: 64 elements + pad
     constexpr int PLANE = 64 * RS;
     constexpr int BUF = 4 * PLANE;              // K hi, K lo, V hi, V lo
@@ -258,9 +282,9 @@ static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const fl
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int h = bhid % H, b = bhid / H;
     const size_t bh = (size_t)b * H + h;
-    const int q0 = blockIdx.y * (NW * 16 * QS) + wave * (16 * QS);
+    const int q0 = qblk * (NW * 16 * QS) + wave * (16 * QS);
     int kv_len = N;
     if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
     const int nkt = (kv_len + 63) / 64;
@@ -353,7 +377,7 @@ static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const fl
                 kl[ks] = *reinterpret_cast<const u32x4*>(Ks + PLANE + ks * 16 * RS + f * 64);
             }
 #pragma unroll
-            for (int term = 0; term < ((DIAG & 8) ? 0 : 3); ++term)
+            for (int term = (HI & 1) ? 2 : 0; term < ((DIAG & 8) ? 0 : 3); ++term)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -426,7 +450,7 @@ static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const fl
                 vl[dt] = u32x4{b0.x, b0.y, b1.x, b1.y};
             }
 #pragma unroll
-            for (int term = 0; term < ((DIAG & 4) ? 0 : 3); ++term)
+            for (int term = (HI & 2) ? 2 : 0; term < ((DIAG & 4) ? 0 : 3); ++term)
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -457,23 +481,35 @@ static __global__ __launch_bounds__(NW * 64) void attn_split_fwd_kernel(const fl
     }
 }
 
-inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
-                                         int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
-                                         const int* o_row_start = nullptr, int o_planar = 0) {
+template <int HI>
+inline hipError_t launch_attention_split_hi(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
+                                            int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens, const int* o_row_start,
+                                            int o_planar) {
     // 128 query rows per workgroup as 8 waves x 16 rows: two waves per SIMD (one's softmax / split arithmetic overlaps the other's
     // MFMAs) sharing one staged K / V tile.  (4 waves x 32 rows: one wave per SIMD, every phase serial: 44 us at C2 against 39;
     // 4 waves x 16 rows: twice the staging per query, 47 us -- tools/probe/attn_probe.hip)
     constexpr int smem = 2 * 4 * 64 * (128 + 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<1, 8>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_fwd_kernel<1, 8, 0, HI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(H * Bp, (N + 127) / 128);
-    hipLaunchKernelGGL((attn_split_fwd_kernel<1, 8>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
+    hipLaunchKernelGGL((attn_split_fwd_kernel<1, 8, 0, HI>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens,
+                       o_row_start, o_planar);
     return hipGetLastError();
+}
+inline hipError_t launch_attention_split(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H, int N,
+                                         int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens = nullptr,
+                                         const int* o_row_start = nullptr, int o_planar = 0, int hi_only = 0) {
+    switch (hi_only & 3) {   // (1..3: diagnostic F5_X3_ABLATE)
+        case 1: return launch_attention_split_hi<1>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
+        case 2: return launch_attention_split_hi<2>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
+        case 3: return launch_attention_split_hi<3>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
+        default: return launch_attention_split_hi<0>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar);
+    }
 }
 
 }  // namespace f5

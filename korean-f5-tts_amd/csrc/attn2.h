@@ -232,7 +232,9 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // query blocks wholly past the sample's own length (padded batches): their output rows are zeroed by the reference
     // (modules.py:540-542; here: never read, the out-projection epilogue masks those rows) -- exit before any barrier
-    if (q_lens && (int)blockIdx.y * 128 >= q_lens[((int)blockIdx.x / H) % nbatch_lens]) return;
+    int bhid, qblk;
+    attn_block_map(bhid, qblk);   // (attn.h: the query blocks of a head run back to back on one XCD)
+    if (q_lens && qblk * 128 >= q_lens[(bhid / H) % nbatch_lens]) return;
     constexpr int NS = 3;
     constexpr int TILE = 64 * 128;      // bytes of one K or V^T tile
     constexpr int STAGE = 2 * TILE;
@@ -243,12 +245,9 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qg = wave >> 1, kh = wave & 1;
     const int l15 = lane & 15, g = lane >> 4;
-    // grid: x = (batch row, head), y = query block -- consecutive workgroup ids (dealt round-robin over the 8 XCDs)
-    // are different heads, so the 8 query blocks that share one head's K/V meet in ONE XCD's L2
-    const int bhid = blockIdx.x;
     const int b = bhid / H, h = bhid - b * H;
     const size_t bh = (size_t)bhid;
-    const int q0 = blockIdx.y * 128 + qg * 32;
+    const int q0 = qblk * 128 + qg * 32;
     int kv_len = N;
     if (kv_lens) kv_len = min(N, kv_lens[b % nbatch_lens]);
     const int nkt = (kv_len + 63) / 64;
@@ -407,18 +406,18 @@ inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, con
 //  batch row b as lens[b % nbl] and may be null)
 inline hipError_t launch_attention_any(hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt, bf16_t* O, int Bp,
                                        int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false) {
+                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false, int /*hi_only*/ = 0) {
     return launch_attention_v2<bf16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const f16_t* Q, const f16_t* K, const f16_t* Vt, f16_t* O, int Bp,
                                        int H, int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false) {
+                                       const int* o_row_start = nullptr, bool /*split16*/ = false, bool /*o_planar*/ = false, int /*hi_only*/ = 0) {
     return launch_attention_v2<f16_t>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 inline hipError_t launch_attention_any(hipStream_t s, const float* Q, const float* K, const float* Vt, float* O, int Bp, int H,
                                        int N, int Npad, const int* kv_lens, int nbl, const int* q_lens = nullptr,
-                                       const int* o_row_start = nullptr, bool split16 = false, bool o_planar = false) {
-    if (split16) return launch_attention_split(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start, o_planar);   // F5_PREC_F16X3
+                                       const int* o_row_start = nullptr, bool split16 = false, bool o_planar = false, int hi_only = 0) {
+    if (split16) return launch_attention_split(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start, o_planar, hi_only);   // F5_PREC_F16X3
     return launch_attention<float>(s, Q, K, Vt, O, Bp, H, N, Npad, kv_lens, nbl, q_lens, o_row_start);
 }
 

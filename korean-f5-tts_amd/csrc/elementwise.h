@@ -562,6 +562,17 @@ static __global__ void split_planar_kernel(float* __restrict__ w, long blocks) {
     }
 }
 
+// Diagnostic (F5_X3_ABLATE): out = (float)(f16)in -- an f32 operand that is not stored split, as plain f16 would see it
+static __global__ void round_f16_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)(f16_t)in[i];
+}
+// Diagnostic (F5_X3_ABLATE, tools/x3_ablate.py): zeroes the lo halves (chunks 4..7 of every 128-byte block) of a split-planar
+// operand in place, which turns the three-product f16x3 contraction into the plain f16 one (a_hi w_hi) for that operand.
+static __global__ void zero_lo_planar_kernel(float* __restrict__ w, long blocks) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < blocks * 4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(w + (i >> 2) * 32)[4 + (i & 3)] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 inline int ew_blocks(long total, int per_block = 256, int cap = 4096) {
     long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;

@@ -22,7 +22,7 @@
 // precision dispatch of one EngineOps<T> member
 #define F5_OPS(e, CALL)                                                  \
     ((e)->cfg.precision == F5_PREC_BF16  ? EngineOps<bf16_t>::CALL       \
-     : (e)->cfg.precision == F5_PREC_F16 ? EngineOps<f16_t>::CALL        \
+     : ((e)->cfg.precision == F5_PREC_F16 || (e)->cfg.precision == F5_PREC_F16P) ? EngineOps<f16_t>::CALL        \
                                          : EngineOps<float>::CALL)
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -45,7 +45,8 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     if (c->heads <= 0 || (c->heads * 64) % 64 != 0 || c->depth <= 0) return fail(F5_EINVAL, "bad heads/depth");
     if (c->mel_dim % 4 || c->text_dim % 4 || c->ff_dim % 8) return fail(F5_EINVAL, "mel_dim/text_dim %% 4, ff_dim %% 8 required");
     if ((2 * c->mel_dim + c->text_dim) % 4) return fail(F5_EINVAL, "2*mel_dim + text_dim must be a multiple of 4");
-    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16 && c->precision != F5_PREC_F16 && c->precision != F5_PREC_F16X3)
+    if (c->precision != F5_PREC_F32 && c->precision != F5_PREC_BF16 && c->precision != F5_PREC_F16 && c->precision != F5_PREC_F16X3 &&
+        c->precision != F5_PREC_F16P)
         return fail(F5_EINVAL, "bad precision");
     if (c->precision == F5_PREC_F16X3 && c->ff_dim % 32)
         return fail(F5_EINVAL, "F5_PREC_F16X3 needs ff_dim %% 32 == 0 (whole 32-element blocks of the split operand layout; got %d)", c->ff_dim);
@@ -59,6 +60,8 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     e->kin_pad = round_up(e->kin, 64);  // whole 128-byte K-tiles for the LDS-DMA GEMM (pad columns stay zero)
     e->modN = (6 * c->depth + 2) * c->dim;
     e->split16 = c->precision == F5_PREC_F16X3;
+    e->io_split = c->precision == F5_PREC_F16P;
+    if (e->split16 && getenv("F5_X3_ABLATE")) e->x3_ablate = atoi(getenv("F5_X3_ABLATE"));
     *out = e;
     return F5_OK;
 }

@@ -21,7 +21,7 @@ static int need(const WeightStore& ws, const std::string& n, std::initializer_li
 // F5_PREC_F16X3: the backbone's GEMM weights (BB) are stored split into f16 hi / lo halves (elementwise.h split_planar_kernel)
 template <typename T, bool BB> static int maybe_split_weight(f5_engine* e, hipStream_t s, T* w, size_t elems) {
     if constexpr (BB && std::is_same_v<T, float>) {
-        if (e->split16) {
+        if (e->split16 || e->io_split) {
             hipLaunchKernelGGL(split_planar_kernel, dim3(ew_blocks((long)(elems / 32))), dim3(256), 0, s, w, (long)(elems / 32));
             HIPCHK(hipGetLastError());
         }
@@ -142,6 +142,11 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
     }
     // input embedding
     CHK(pack_linear_bb<T>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj));
+    auto zlo_w = [&](T* wp, size_t elems) {   // diagnostic F5_X3_ABLATE: plain f16 weights (lo halves of the split layout zeroed)
+        if constexpr (std::is_same_v<T, float>)
+            hipLaunchKernelGGL(zero_lo_planar_kernel, dim3(ew_blocks((long)elems / 8)), dim3(256), 0, s, wp, (long)(elems / 32));
+    };
+    if (e->x3_ablate & 64) zlo_w(P.in_proj.w, (size_t)P.in_proj.N * P.in_proj.ldw);
     const int cpg = D / 16;
     P.conv_kp = round_up(31 * cpg, GEMM_ROW_BYTES / (int)sizeof(T));   // whole K-tiles, zero padded (convpos.h)
     for (int j = 0; j < 2; ++j) {
@@ -152,6 +157,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(ew_blocks((long)D * P.conv_kp)), dim3(256), 0, s, w->p,
                            P.conv_w[j], (long)D, cpg, 31, P.conv_kp);
         if (conv_split(e)) CHK((maybe_split_weight<T, true>(e, s, P.conv_w[j], (size_t)D * P.conv_kp)));   // F5_PREC_F16X3 (convpos.h SPLIT)
+        if (conv_split(e) && (e->x3_ablate & 128)) zlo_w(P.conv_w[j], (size_t)D * P.conv_kp);
         CHK(copy_vec(e, s, p + ".bias", {D}, &P.conv_b[j]));
     }
     // transformer
@@ -166,13 +172,27 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         CHK(pack_linear_bb<T>(e, s, at + ".to_out.0.weight", at + ".to_out.0.bias", D, inner, &b.out));
         CHK(pack_linear_bb<T>(e, s, ff + ".ff.0.0.weight", ff + ".ff.0.0.bias", F, D, &b.ff1));
         CHK(pack_linear_bb<T>(e, s, ff + ".ff.2.weight", ff + ".ff.2.bias", D, F, &b.ff2));
+        if constexpr (std::is_same_v<T, float>) {   // diagnostic F5_X3_ABLATE: plain f16 weights (lo halves zeroed) for a class
+            auto zlo = [&](LinW<T>& L) {
+                const long blocks = (long)L.N * L.ldw / 32;
+                hipLaunchKernelGGL(zero_lo_planar_kernel, dim3(ew_blocks(blocks * 4)), dim3(256), 0, s, L.w, blocks);
+            };
+            if (e->x3_ablate & 1) zlo(b.qkv);
+            if (e->x3_ablate & 8) zlo(b.out);
+            if (e->x3_ablate & 16) zlo(b.ff1);
+            if (e->x3_ablate & 32) zlo(b.ff2);
+            HIPCHK(hipGetLastError());
+        }
         if (dit) {
             modp.push_back(p + ".attn_norm.linear");
         } else {
             CHK(copy_vec(e, s, p + ".1.g", {D}, &b.norm1_g));
             CHK(copy_vec(e, s, p + ".3.g", {D}, &b.norm2_g));
             if (i >= c.depth / 2 && e->ws.get(p + ".0.weight"))
+            {
                 CHK(pack_linear_bb<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
+                if (e->io_split) CHK((pack_linear<float, true>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip_f)));
+            }
         }
     }
     if (dit) {
@@ -199,6 +219,22 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         CHK(copy_vec(e, s, "norm_out.g", {D}, &P.norm_out_g));
     }
     CHK(pack_linear_bb<T>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out));
+    if (e->io_split) {   // F5_PREC_F16P: the input / output layers once more, as split-planar f32 operands
+        CHK((pack_linear<float, true>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj_f)));
+        CHK((pack_linear<float, true>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out_f)));
+        P.conv_kp_f = round_up(31 * cpg, GEMM_ROW_BYTES / (int)sizeof(float));
+        for (int j = 0; j < 2; ++j) {
+            const std::string p = "input_embed.conv_pos_embed.conv1d." + std::to_string(j * 2);
+            const Tensor* w = nullptr;
+            CHK(need(e->ws, p + ".weight", {D, cpg, 31}, &w));
+            CHK(dev_alloc(e, &P.conv_w_f[j], (size_t)D * P.conv_kp_f));
+            hipLaunchKernelGGL((conv_pack_kernel<float>), dim3(ew_blocks((long)D * P.conv_kp_f)), dim3(256), 0, s, w->p,
+                               P.conv_w_f[j], (long)D, cpg, 31, P.conv_kp_f);
+            // (dims whose 32-deep K blocks straddle taps keep the exact-f32 MFMA kernel: convpos_can_split)
+            if (convpos_can_split(D)) CHK((maybe_split_weight<float, true>(e, s, P.conv_w_f[j], (size_t)D * P.conv_kp_f)));
+        }
+    }
+    if (e->x3_ablate & 256) zlo_w(P.proj_out.w, (size_t)P.proj_out.N * P.proj_out.ldw);
     HIPCHK(hipGetLastError());
     return F5_OK;
 }
@@ -229,7 +265,7 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.tx_h1 = a.take<float>((size_t)B * N * 2 * Dt);
     w.grn_part = a.take<float>((size_t)B * GRN_P * 2 * Dt);
     w.uc = a.take<float>((size_t)N * Dt);
-    w.acat = a.take<T>(Bp * N * e->kin_pad);
+    w.acat = a.take<T>(Bp * N * e->kin_pad * (e->io_split ? sizeof(float) / sizeof(T) : 1));   // (F5_PREC_F16P packs the input rows as f32)
     w.h = a.take<float>(rows * D);
     w.c1 = a.take<float>(rows * D);
     w.x = a.take<float>(rows * D);
@@ -250,7 +286,7 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.skips = nullptr;
     w.pred_all = nullptr;
     if (c.backbone == F5_BACKBONE_UNETT) {
-        w.cat2 = a.take<T>(rows * 2 * D);
+        w.cat2 = a.take<T>(rows * 2 * D * (e->io_split ? sizeof(float) / sizeof(T) : 1));   // (F5_PREC_F16P: f32 rows)
         w.skips = a.take<float>(rows * D * (c.depth / 2));
         w.pred_all = a.take<float>(rows * mel);
     }
@@ -353,6 +389,29 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     Prof& pr = e->prof;
     const double rows_fl = pk ? pk.rows_host : (double)rows;
     auto gflops = [&](double n, double k) { return 2.0 * rows_fl * n * k; };
+    const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
+    if (e->io_split) {
+        // F5_PREC_F16P: [y, cond, text] packed as f32 rows; input projection and conv position embedding as split-f16 products on f32
+        // operands (what the f16 blocks then see is x, the f32 residual stream, exactly as in F5_PREC_F16X3)
+        float* acat_f = reinterpret_cast<float*>(w.acat);
+        pr.begin(PC_MISC, s);
+        hipLaunchKernelGGL((pack_input_kernel<float>), dim3(ew_blocks((long)rows * e->kin / 4)), dim3(256), 0, s, y, cond,
+                           text_first, text_second, acat_f, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first, pk.rowmap, ml,
+                           lens_dev);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(D, e->kin));
+        HIPCHK(launch_gemm<float>(s, acat_f, e->kin_pad, P.in_proj_f.w, P.in_proj_f.ldw, rows, D, e->kin_pad,
+                                  EpiStore<float>{w.h, D, P.in_proj_f.b, F5_ACT_NONE}, -1, ml, mh, GemmConv{}, 1));
+        pr.end(s);
+        const bool cs = convpos_can_split(D);
+        pr.begin(PC_CONV, s, conv_fl);
+        HIPCHK(launch_convpos<float>(s, w.h, P.conv_w_f[0], P.conv_kp_f, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start, cs));
+        pr.end(s);
+        pr.begin(PC_CONV, s, conv_fl);
+        HIPCHK(launch_convpos<float>(s, w.c1, P.conv_w_f[1], P.conv_kp_f, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start, cs));
+        pr.end(s);
+    } else {
     // input embedding
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL((pack_input_kernel<T>), dim3(ew_blocks((long)rows * e->kin / 4)), dim3(256), 0, s, y, cond,
@@ -360,20 +419,37 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
                        lens_dev);
     KCHK();
     pr.end(s);
+    auto ablate_round = [&](int bit, const float* src, float* dst, long n) -> const float* {   // diagnostic F5_X3_ABLATE: an unsplit f32 operand as f16 sees it
+        if (!(e->x3_ablate & bit)) return src;
+        hipLaunchKernelGGL(round_f16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, src, dst, n);
+        return dst;
+    };
+    if constexpr (std::is_same_v<T, float>) ablate_round(64, w.acat, w.acat, (long)rows * e->kin_pad);
     pr.begin(PC_GEMM, s, gflops(D, e->kin));
     HIPCHK(egemm<T>(e, s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows, D, e->kin_pad,
                           EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}, -1, ml, mh));
     pr.end(s);
-    const double conv_fl = 2.0 * rows_fl * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);
-    HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
+    // (ablation: conv 1 reads a rounded COPY of h -- w.x is free until conv 2 writes it -- because h itself is conv 2's f32 residual)
+    const float* conv1_in = ablate_round(128, w.h, w.x, (long)rows * D);
+    HIPCHK(launch_convpos<T>(s, conv1_in, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
     pr.end(s);
+    ablate_round(128, w.c1, w.c1, (long)rows * D);
     pr.begin(PC_CONV, s, conv_fl);
     HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
     pr.end(s);
+    }
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
     const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh are written pre-split (the A operands of the block GEMMs)
+    auto ablate_a = [&](int bit, T* a, int k) {   // diagnostic F5_X3_ABLATE: the class's A operand as plain f16 (lo halves zeroed)
+        if constexpr (std::is_same_v<T, float>) {
+            if (e->x3_ablate & bit) {
+                const long blocks = (long)rows * k / 32;
+                hipLaunchKernelGGL(zero_lo_planar_kernel, dim3(ew_blocks(blocks * 4)), dim3(256), 0, s, a, blocks);
+            }
+        }
+    };
     // weight prefetch from the LayerNorm launches (see layernorm_kernel): only where the GEMMs are latency-bound
     const bool wpf = rows <= 4096 && !(getenv("F5_WEIGHT_PREFETCH") && getenv("F5_WEIGHT_PREFETCH")[0] == '0');
     for (int l = 0; l < c.depth; ++l) {
@@ -386,14 +462,17 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
                                           (const char*)bw.out.w, (size_t)D * bw.out.ldw * sizeof(T)} : Prefetch{}, ml, pl);
         KCHK();
         pr.end(s);
+        ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
                               -1, ml, mh, pl));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl,
+                                    (e->x3_ablate >> 1) & 3));
         pr.end(s);
+        ablate_a(8, w.ao, inner);
         pr.begin(PC_GEMM, s, gflops(D, inner));
         HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
                               EpiGateRes{w.x, w.x, D, bw.out.b, m + 2 * D, mod_stride, N, gate_lens}, -1, ml, mh, pl));
@@ -405,20 +484,35 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
                                           (const char*)bw.ff2.w, (size_t)D * bw.ff2.ldw * sizeof(T)} : Prefetch{}, ml, pl);
         KCHK();
         pr.end(s);
+        ablate_a(16, w.xn, D);
         pr.begin(PC_GEMM, s, gflops(F, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH, pl}, -1, ml, mh, pl));
         pr.end(s);
+        ablate_a(32, w.ffh, F);
         pr.begin(PC_GEMM, s, gflops(D, F));
         HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
                               EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh, pl));
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
+    if (e->io_split) {   // F5_PREC_F16P: final norm to f32 (pre-split rows in c1, free since the conv embedding) + split output projection
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((layernorm_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.c1, D, rows, D, 1e-6f, mf,
+                           mf + D, mod_stride, N, 1, Prefetch{}, ml, 1);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gflops(mel, D));
+        HIPCHK(launch_gemm<float>(s, w.c1, D, P.proj_out_f.w, P.proj_out_f.ldw, rows, mel, D,
+                                  EpiStore<float>{w.pred, mel, P.proj_out_f.b, F5_ACT_NONE}, -1, ml, mh, GemmConv{}, 2));
+        pr.end(s);
+        return F5_OK;
+    }
     pr.begin(PC_LN, s);
     hipLaunchKernelGGL((layernorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, 1e-6f, mf,
                        mf + D, mod_stride, N, 1, Prefetch{}, ml, pl);
     KCHK();
     pr.end(s);
+    ablate_a(256, w.xn, D);
     pr.begin(PC_GEMM, s, gflops(mel, D));
     HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D,
                           EpiStore<float>{w.pred, mel, P.proj_out.b, F5_ACT_NONE}, -1, ml, mh, pl));
@@ -439,6 +533,27 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     const int rows_in = Bp * N, rows = Bp * Nt;
     Prof& pr = e->prof;
     auto gfl = [&](double r, double n, double k) { return 2.0 * r * n * k; };
+    const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
+    float* emb = w.skips;  // free until the layer loop pushes the first skip; conv input and output must not alias
+    if (e->io_split) {   // F5_PREC_F16P: input projection + conv position embedding as split-f16 products on f32 operands (run_dit_forward)
+        float* acat_f = reinterpret_cast<float*>(w.acat);
+        pr.begin(PC_MISC, s);
+        hipLaunchKernelGGL((pack_input_kernel<float>), dim3(ew_blocks((long)rows_in * e->kin / 4)), dim3(256), 0, s, y, cond,
+                           text_first, text_second, acat_f, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows_in, D, e->kin));
+        HIPCHK(launch_gemm<float>(s, acat_f, e->kin_pad, P.in_proj_f.w, P.in_proj_f.ldw, rows_in, D, e->kin_pad,
+                                  EpiStore<float>{w.h, D, P.in_proj_f.b, F5_ACT_NONE}, -1, nullptr, 0, GemmConv{}, 1));
+        pr.end(s);
+        const bool cs = convpos_can_split(D);
+        pr.begin(PC_CONV, s, conv_fl);
+        HIPCHK(launch_convpos<float>(s, w.h, P.conv_w_f[0], P.conv_kp_f, P.conv_b[0], nullptr, w.c1, Bp, N, D, nullptr, B, nullptr, cs));
+        pr.end(s);
+        pr.begin(PC_CONV, s, conv_fl);
+        HIPCHK(launch_convpos<float>(s, w.c1, P.conv_w_f[1], P.conv_kp_f, P.conv_b[1], w.h, emb, Bp, N, D, nullptr, B, nullptr, cs));
+        pr.end(s);
+    } else {
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL((pack_input_kernel<T>), dim3(ew_blocks((long)rows_in * e->kin / 4)), dim3(256), 0, s, y, cond,
                        text_first, text_second, w.acat, e->kin_pad, B, Bp, N, mel, c.text_dim, drop_cond_first);
@@ -448,14 +563,13 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     HIPCHK(egemm<T>(e, s, w.acat, e->kin_pad, P.in_proj.w, P.in_proj.ldw, rows_in, D, e->kin_pad,
                           EpiStore<float>{w.h, D, P.in_proj.b, F5_ACT_NONE}));
     pr.end(s);
-    const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
     pr.begin(PC_CONV, s, conv_fl);   // unett.py:99-100: conv_pos_embed is called WITHOUT a mask
     HIPCHK(launch_convpos<T>(s, w.h, P.conv_w[0], P.conv_kp, P.conv_b[0], nullptr, w.c1, Bp, N, D, nullptr, B, nullptr, conv_split(e)));
     pr.end(s);
     pr.begin(PC_CONV, s, conv_fl);
-    float* emb = w.skips;  // free until the layer loop pushes the first skip; conv input and output must not alias
     HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, emb, Bp, N, D, nullptr, B, nullptr, conv_split(e)));
     pr.end(s);
+    }
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL(unett_assemble_kernel, dim3(ew_blocks((long)rows * D / 4)), dim3(256), 0, s, emb, temb, temb_stride, w.x,
                        Bp, N, D);
@@ -472,6 +586,17 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         } else {
             const float* skip = w.skips + (size_t)(c.depth - 1 - l) * rows * D;   // LIFO (skips.pop())
             pr.begin(PC_MISC, s);
+            if (e->io_split) {   // F5_PREC_F16P: [x | skip] is the un-normalised f32 stream: split-f16 products on f32 rows
+                float* cat_f = reinterpret_cast<float*>(w.cat2);
+                hipLaunchKernelGGL((cat2_kernel<float>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, cat_f,
+                                   (long)rows, D);
+                KCHK();
+                pr.end(s);
+                pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
+                HIPCHK(launch_gemm<float>(s, cat_f, 2 * D, bw.skip_f.w, bw.skip_f.ldw, rows, D, 2 * D,
+                                          EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}, -1, nullptr, 0, GemmConv{}, 1));
+                pr.end(s);
+            } else {
             hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, w.cat2,
                                (long)rows, D);
             KCHK();
@@ -480,6 +605,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
                                   EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
             pr.end(s);
+            }
         }
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g, pl);
@@ -508,6 +634,17 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}, -1, nullptr, 0, pl));
         pr.end(s);
     }
+    if (e->io_split) {   // F5_PREC_F16P: final norm to pre-split f32 rows (in the skip stack's first slot: every skip has been popped) + split projection
+        float* xn_f = w.skips;
+        pr.begin(PC_LN, s);
+        hipLaunchKernelGGL((xrmsnorm_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, xn_f, D, rows, D, P.norm_out_g, 1);
+        KCHK();
+        pr.end(s);
+        pr.begin(PC_GEMM, s, gfl(rows, mel, D));
+        HIPCHK(launch_gemm<float>(s, xn_f, D, P.proj_out_f.w, P.proj_out_f.ldw, rows, mel, D,
+                                  EpiStore<float>{w.pred_all, mel, P.proj_out_f.b, F5_ACT_NONE}, -1, nullptr, 0, GemmConv{}, 2));
+        pr.end(s);
+    } else {
     pr.begin(PC_LN, s);
     hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, P.norm_out_g, pl);
     KCHK();
@@ -515,6 +652,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     pr.begin(PC_GEMM, s, gfl(rows, mel, D));
     HIPCHK(egemm<T>(e, s, w.xn, D, P.proj_out.w, P.proj_out.ldw, rows, mel, D, EpiStore<float>{w.pred_all, mel, P.proj_out.b, F5_ACT_NONE}, -1, nullptr, 0, pl));
     pr.end(s);
+    }
     pr.begin(PC_MISC, s);
     hipLaunchKernelGGL(strip_first_token_kernel, dim3(ew_blocks((long)rows_in * mel / 4)), dim3(256), 0, s, w.pred_all, w.pred, Bp, N, mel);
     KCHK();

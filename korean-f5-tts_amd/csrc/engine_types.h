@@ -144,6 +144,7 @@ template <typename T> struct LinW {
 
 template <typename T> struct BlockW {
     LinW<T> qkv, out, ff1, ff2, skip;  // skip: UNetT concat projection (no bias)
+    LinW<float> skip_f;                // F5_PREC_F16P: the concat projection reads the RAW residual stream: split-planar f32 copy
     float* norm1_g = nullptr;          // UNetT RMSNorm gains
     float* norm2_g = nullptr;
 };
@@ -163,6 +164,10 @@ template <typename T> struct Packed {
     int conv_kp = 0;
     std::vector<BlockW<T>> blocks;
     LinW<T> proj_out;
+    // F5_PREC_F16P: split-planar f32 copies of the input / output layers' weights (gemm2.h MODE 3 / 5, convpos.h SPLIT)
+    LinW<float> in_proj_f, proj_out_f;
+    float* conv_w_f[2] = {nullptr, nullptr};
+    int conv_kp_f = 0;
     float* norm_out_g = nullptr;  // UNetT
     // aux tables
     float *rope_cos = nullptr, *rope_sin = nullptr, *time_freqs = nullptr, *text_pos = nullptr;
@@ -172,7 +177,12 @@ template <typename T> struct Packed {
 struct f5_engine {
     f5_config cfg{};
     int inner = 0, kin = 0, kin_pad = 0, modN = 0;
+    bool io_split = false;     // F5_PREC_F16P: the f16 engine with its input / output layers as split-f16 products on f32 operands
     bool split16 = false;      // F5_PREC_F16X3: the f32 engine with the backbone GEMMs on the f16 pipe (gemm2.h MODE 3)
+    // Diagnostic (F5_X3_ABLATE=<bitmask>, F5_PREC_F16X3 only; tools/x3_ablate.py): contraction classes run with plain f16 products
+    // (hi x hi only) instead of the three split products: 1 QKV, 2 attention K Q^T, 4 attention V^T P^T, 8 out-proj, 16 FF1, 32 FF2,
+    // 64 input projection, 128 conv position embedding, 256 output projection
+    int x3_ablate = 0;
     WeightStore ws;
     std::vector<void*> owned;  // packed buffers
     Packed<float> pf;

@@ -10,6 +10,9 @@
 namespace f5 {
 
 enum GemmCfg { G2_128x128_8W = 2, G2_128x64_8W = 9, G2_64x64_4W = 8, G2_128x192_8W = 10, G2_256x128_8W = 13, G3_256x256_PP = 20 };
+// (Tried for the many-row block GEMMs and dropped, tools/block_gemm_time.py: 128x128 tiles with a 2-stage ring = 64 KB of LDS, two
+//  workgroups per CU so that one's epilogue runs under the other's K loop -- 8 waves: 939 us per block of 32,768 rows against 794
+//  for the tiles chosen below, QKV 420 against 284 us; 4 waves: 1,086 us.)
 
 // cost = rounds of workgroups over the 256 CUs x the time of one tile of that shape (us at K = 1024, measured with
 // tools/gemm2_sweep.py on a full chip: the per-K-step time grows much more slowly than the tile area, so the largest

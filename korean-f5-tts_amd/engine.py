@@ -56,7 +56,7 @@ class Engine:
     """One f5_engine handle bound to one device (one process per GPU; handles are not shared across streams)."""
 
     def __init__(self, arch: dict, text_num_embeds: int, mel_dim: int = 100, *, backbone: str = "DiT",
-                 precision: str = "bf16", device="cuda", max_pos: int = 8192):
+                 precision: str = "f16p", device="cuda", max_pos: int = 8192):
         self.lib = _lib.load()  # raises if the HIP library is not built
         if not torch.cuda.is_available():
             raise _lib.F5Error("no GPU visible: the F5-TTS engine has no CPU path")

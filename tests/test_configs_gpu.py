@@ -52,9 +52,9 @@ def _ragged_inputs(durs, seed):
 
 
 def test_c2_size_every_precision_vs_oracle():
-    """The benchmarked workload itself (bench.py C2).  f32 and f16x3 (f32 data flow, split-f16 GEMM products) must meet the 1e-3
-    parity bar against the CPU oracle; the bf16 / f16 speed precisions are measured against the same oracle trajectory,
-    printed and gated at ~2x."""
+    """The benchmarked workload itself (bench.py C2).  f32, f16x3 (f32 data flow, split-f16 GEMM products) and f16p (f16 blocks,
+    split-f16 input / output layers: bench.py's timed precision) must meet the 1e-3 parity bar against the CPU oracle -- f16p with
+    a 2x margin; the bf16 / f16 speed precisions are measured against the same oracle trajectory, printed and gated at ~2x."""
     _threads()
     arch = P.config.F5TTS_BASE
     sd = P.weights.synthetic_state_dict(P.weights.dit_param_shapes(arch, NV))
@@ -67,13 +67,14 @@ def test_c2_size_every_precision_vs_oracle():
         o_out, o_traj = O.sample(sd, arch, cond, text, 1024, **kw)
     t_or = time.time() - t0
     errs = {}
-    for prec in ("f32", "f16x3", "f16", "bf16"):
+    for prec in ("f32", "f16x3", "f16p", "f16", "bf16"):
         out, traj = _model(P.DiT, arch, sd, prec).sample(cond, text, 1024, **kw)
         errs[prec] = ((traj.cpu() - o_traj).abs().max().item(), (out.cpu() - o_out)[:, 256:].abs().max().item())
     print(f"[C2 size, N=1024 NFE=16] oracle {t_or:.0f} s; traj / generated-mel Linf vs oracle: " +
           ", ".join(f"{p} {e[0]:.3e} / {e[1]:.3e}" for p, e in errs.items()) +
           f" (state magnitude {o_traj.abs().max().item():.2f})")
     assert errs["f32"][0] < TOL_PARITY and errs["f16x3"][0] < TOL_PARITY
+    assert errs["f16p"][0] < TOL_PARITY / 2 and errs["f16p"][1] < TOL_PARITY / 2, "the benchmarked precision meets 1e-3 with a 2x margin"
     for prec in ("f16", "bf16"):
         assert errs[prec][0] < TOL_C2[prec]
 
@@ -102,11 +103,22 @@ def test_c3_chunked_base_batch_vs_oracle(monkeypatch):
     assert e_all < TOL_PARITY
     for i, (d, r) in enumerate(zip(durs, refs)):
         assert torch.equal(out[i, :r].cpu(), cond[i, :r]), "prompt frames are returned verbatim (cfm.py:221-223)"
-    for prec in ("f16x3", "f16", "bf16"):
-        o16, t16 = _model(P.DiT, arch, sd, prec).sample(cond, text, torch.tensor(durs), **kw)
+    m32 = _model(P.DiT, arch, sd, "f32")
+    for prec in ("f16x3", "f16p", "f16", "bf16"):
+        mp = _model(P.DiT, arch, sd, prec)
+        o16, t16 = mp.sample(cond, text, torch.tensor(durs), **kw)
         e16 = (t16.cpu() - o_traj).abs().max().item()
         print(f"[C3 chunked] {prec} traj Linf {e16:.3e}")
-        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C2[prec])
+        # ONE Euler step of size 1 is the worst case for a 16-bit forward: y1 = y0 + (3 pred_c - 2 pred_u), nothing averages.  f16p
+        # (f16 products inside the 22 blocks) is held to the parity bar on a real solve below, and to 2x the bar here
+        assert e16 < (TOL_PARITY if prec == "f16x3" else 2 * TOL_PARITY if prec == "f16p" else TOL_C2[prec])
+        if prec == "f16p":   # 8 Euler steps on the same two-chunk geometry, against the f32 engine (pinned to the oracle just above)
+            kw8 = dict(kw, steps=8, use_epss=True)
+            _, tr = m32.sample(cond, text, torch.tensor(durs), **kw8)
+            _, tp = mp.sample(cond, text, torch.tensor(durs), **kw8)
+            e8 = (tp - tr).abs().max().item()
+            print(f"[C3 chunked] f16p, 8 Euler steps, traj Linf vs the f32 engine {e8:.3e}")
+            assert e8 < TOL_PARITY / 2
 
 
 def test_c3_full_job_properties(monkeypatch):
@@ -151,7 +163,7 @@ def test_c3_attn_mask_packed_rows_match_padded_rows(monkeypatch):
     kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, lens=torch.tensor(refs))
     valid = O.lens_to_mask(torch.tensor(durs), 1024)[..., None].to(DEV)
     res = {}
-    for prec in ("f32", "bf16"):
+    for prec in ("f32", "bf16", "f16p"):
         monkeypatch.setenv("F5_PACK_ROWS", "1")
         _, tp = _model(P.DiT, arch, sd, prec).sample(cond, text, torch.tensor(durs), **kw)
         monkeypatch.setenv("F5_PACK_ROWS", "0")
@@ -160,11 +172,11 @@ def test_c3_attn_mask_packed_rows_match_padded_rows(monkeypatch):
         assert torch.isfinite(tp).all()
         pad = ~valid.expand_as(tp[0])
         assert torch.equal(tp[-1][pad], tp[0][pad]), "frames past a sample's own length keep their initial value"
-    print(f"[C3 attn_mask, packed vs padded rows, B=16 Base dims] traj Linf on valid frames: f32 {res['f32']:.3e}, bf16 {res['bf16']:.3e}")
+    print(f"[C3 attn_mask, packed vs padded rows, B=16 Base dims] traj Linf on valid frames: f32 {res['f32']:.3e}, bf16 {res['bf16']:.3e}, f16p {res['f16p']:.3e}")
     # bit for bit, in the 16-bit precision too: the packed run steps other chunks (11 + 5 utterances against 8 + 8) through
     # other GEMM tiles, and a row's result must not depend on either (the library is built with -ffp-contract=off for
     # exactly this: hipcc's fused multiply-adds differed between instantiations of one epilogue, build.py)
-    assert res["f32"] == 0.0 and res["bf16"] == 0.0
+    assert res["f32"] == 0.0 and res["bf16"] == 0.0 and res["f16p"] == 0.0
 
 
 def test_c5_base_unett_batch_vs_oracle():
@@ -186,8 +198,8 @@ def test_c5_base_unett_batch_vs_oracle():
     e = (traj.cpu() - o_traj).abs().max().item()
     print(f"[C5 UNetT Base, B=8 N=1024, 1 step] oracle {t_or:.0f} s; f32 traj Linf {e:.3e}")
     assert e < TOL_PARITY
-    for prec in ("f16x3", "f16", "bf16"):
+    for prec in ("f16x3", "f16p", "f16", "bf16"):
         o16, t16 = _model(P.UNetT, arch, sd, prec).sample(cond, text, N, **kw)
         e16 = (t16.cpu() - o_traj).abs().max().item()
         print(f"[C5 UNetT Base] {prec} traj Linf {e16:.3e}")
-        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C2[prec])
+        assert e16 < (TOL_PARITY if prec == "f16x3" else 2 * TOL_PARITY if prec == "f16p" else TOL_C2[prec])   # (one step of size 1: see C3)

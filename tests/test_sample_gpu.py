@@ -59,7 +59,7 @@ def valid_frames(meta, a):
     return (torch.arange(N)[None, :] < d[:, None])[..., None]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])     # the two precisions held to the 1e-3 parity bar (f16x3: split-f16 products)
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16p"])     # the precisions held to the 1e-3 parity bar (f16x3: split-f16 products; f16p: f16 blocks + split-f16 I/O layers)
 @pytest.mark.parametrize("name", CASES)
 def test_sample_parity_f32_vs_reference_vectors(name, prec):
     meta, a = load_golden(name)
