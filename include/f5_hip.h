@@ -110,7 +110,10 @@ int f5_dit_forward(f5_engine* e, const float* x, const float* cond, const int64_
  *   F.pad(cond, (0, 0, 0, N - cond_seq_len)), cfm.py:145; cond_frames = 0 is no_ref_audio), cond_mask u8[B, N], y0 f32[B, N, mel],
  *   text i64[B, nt], lens HOST int32[B] = per-sample durations or NULL when B == 1 (cfm.py:155-158),
  *   out f32[B, N, mel], traj f32[steps + 1, B, N, mel] or NULL.
- * The text embeddings are computed once per call (the reference's per-sample() cache, dit.py:244-269). */
+ * The text embeddings are computed once per call (the reference's per-sample() cache, dit.py:244-269).
+ * Frames past a sample's own length: with attn_mask_enabled and B > 1 the backbone runs on the valid rows only (RowPack), and those
+ * frames keep y0's value in `out` / `traj` (the reference integrates them to values nobody reads, cfm.py:160-191); F5_PACK_ROWS=0
+ * computes them as the reference does.  With attn_mask_enabled = 0 (every shipped config) all frames match the reference. */
 int f5_sample(f5_engine* e, const float* cond, int32_t cond_frames, const uint8_t* cond_mask, const float* y0,
               const int64_t* text, int32_t nt, const float* t_host, int32_t steps, float cfg_strength,
               const int32_t* lens_host, int32_t B, int32_t N, float* out, float* traj, f5_stream stream);

@@ -69,6 +69,17 @@ __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, floa
     *reinterpret_cast<f16x4*>(p) = v;
 }
 
+// four f32 -> 8 bytes of 16-bit type TO (the value store4 would write)
+template <typename TO> __device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d);
+template <> __device__ __forceinline__ u32x2 pack4<bf16_t>(float a, float b, float c, float d) {
+    bf16x4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    return __builtin_bit_cast(u32x2, v);
+}
+template <> __device__ __forceinline__ u32x2 pack4<f16_t>(float a, float b, float c, float d) {
+    f16x4 v = {(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
+    return __builtin_bit_cast(u32x2, v);
+}
+
 // ---- F5_PREC_F16X3 helpers: x = hi + lo with hi = f16(x), lo = f16(x - hi) (gemm2.h MODE 3, attn.h) ----
 __device__ __forceinline__ void split4_f16(const u32x4& c, u32x2& hi, u32x2& lo) {
     typedef __attribute__((ext_vector_type(2))) float v2f;

@@ -55,6 +55,16 @@ template <> struct Mma<float> {
 //   void   store(RowCtx, ColCtx, v, Pre)
 //   TRowCtx trow(m, M) / TColCtx tcol(n)               transposed orientation: v[r] = C[m + r][n]      (m % 4 == 0)
 //   void   tstore(TRowCtx, TColCtx, v)                 -- only reached if tile_transposed() can be true
+// STAGED stores (gemm3.h, many-row tiles).  A lane of an MFMA accumulator owns 4 columns of 16 different rows, so a fragment-order
+// store instruction writes 16 pieces of 32 (16-bit output) or 64 (f32) contiguous bytes: measured 2.4-3.7 TB/s against 5.8-6.7 for
+// whole rows (tools/store_pattern.py).  An epilogue with  kStaged = true  turns a wave's 128 x 64 tile through 16 KiB of LDS itself
+// (fragment order in, rows out: every store instruction writes whole 128-byte lines) and is written so that every operand load
+// of the tile is in flight at once and nothing branches around a store -- hipcc puts `s_waitcnt vmcnt(0)` in front of every store
+// that follows a conditional load, which made the first generic form of this one round trip per row:
+//   bool staged_ok(bool transposed)                      once per tile (wave-uniform)
+//   void staged<MI, NJ>(slice, lane, mw, nw, acc, transposed)
+// Results are bit-identical to store() / tstore().  16-byte chunk c of staging row r lives in slot c ^ (r & 7) (128-byte rows) or
+// c ^ (r & 15) (256-byte rows); a wave only reads what it wrote itself, so no barrier is involved.
 struct NoCtx {};
 
 // ACT >= 0 fixes the activation at compile time.  This matters more than it looks: with a run-time `act` every one of
@@ -81,6 +91,34 @@ template <typename TO, int ACT = -1> struct EpiStore {  // out = act(acc + bias)
         const int a = ACT >= 0 ? ACT : act;
         store4_at(r.p, c.n, planar, apply_act(v[0] + c.b.x, a), apply_act(v[1] + c.b.y, a), apply_act(v[2] + c.b.z, a),
                   apply_act(v[3] + c.b.w, a));
+    }
+    static constexpr bool kStaged = sizeof(TO) == 2;
+    __device__ __forceinline__ bool staged_ok(bool transposed) const { return !transposed; }
+    template <int MI, int NJ>
+    __device__ __forceinline__ void staged(char* slice, int lane, int mw, int nw, const f32x4 (&acc)[MI][NJ], bool) const {
+        if constexpr (sizeof(TO) == 2) {
+            static_assert(MI == 8 && NJ == 4, "128 x 64 wave tile");
+            const int l15 = lane & 15, g = lane >> 4, a = ACT >= 0 ? ACT : act;
+            float4 bj[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bj[j] = bias ? *reinterpret_cast<const float4*>(bias + nw + j * 16 + g * 4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const f32x4 v = acc[i][j];
+                    const int r = i * 16 + l15;
+                    *reinterpret_cast<u32x2*>(slice + r * 128 + (((j * 2 + (g >> 1)) ^ (r & 7)) << 4) + ((g & 1) << 3)) =
+                        pack4<TO>(apply_act(v[0] + bj[j].x, a), apply_act(v[1] + bj[j].y, a), apply_act(v[2] + bj[j].z, a), apply_act(v[3] + bj[j].w, a));
+                }
+            const int rr = lane >> 3, ch = lane & 7;
+            TO* dst = out + (size_t)(mw + rr) * ldo + nw + ch * 8;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int r = p * 8 + rr;
+                *reinterpret_cast<u32x4*>(dst + (size_t)p * 8 * ldo) = *reinterpret_cast<const u32x4*>(slice + r * 128 + ((ch ^ (r & 7)) << 4));
+            }
+        }
     }
     __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
     __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
@@ -138,6 +176,55 @@ struct EpiGateRes {
     __device__ __forceinline__ NoCtx trow(int, int) const { return {}; }
     __device__ __forceinline__ NoCtx tcol(int) const { return {}; }
     __device__ __forceinline__ void tstore(const NoCtx&, const NoCtx&, f32x4) const {}
+    // Staged form: the RAW accumulators are turned (two halves of 64 rows x 256 B); a lane then owns 4 columns of one row per step:
+    // 16 lanes x 16 B = one 256-byte piece of a row of x, read and written whole.  The 16 residual loads of a half are requested
+    // before the half is staged; the (at most two) batch rows a half touches have their gate vectors and lengths loaded once.
+    static constexpr bool kStaged = true;
+    __device__ __forceinline__ bool staged_ok(bool transposed) const { return !transposed && rows_per_batch >= 64; }
+    template <int MI, int NJ>
+    __device__ __forceinline__ void staged(char* slice, int lane, int mw, int nw, const f32x4 (&acc)[MI][NJ], bool) const {
+        static_assert(MI == 8 && NJ == 4, "128 x 64 wave tile");
+        const int l15 = lane & 15, g = lane >> 4, rr = lane >> 4, ch = lane & 15;
+        const int n = nw + ch * 4;
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int mb = mw + half * 64;
+            const int b0 = mb / rows_per_batch, b1 = (mb + 63) / rows_per_batch;
+            const int m0 = b0 * rows_per_batch, m1 = b1 * rows_per_batch;   // first rows of the two batch rows (m1 == m0 when there is one)
+            float4 g0 = make_float4(1, 1, 1, 1), g1 = g0;
+            if (gate) {
+                g0 = *reinterpret_cast<const float4*>(gate + (size_t)b0 * gate_stride + n);
+                g1 = *reinterpret_cast<const float4*>(gate + (size_t)b1 * gate_stride + n);
+            }
+            int len0 = 0x7fffffff, len1 = 0x7fffffff;
+            if (lens) { len0 = lens[b0]; len1 = lens[b1]; }
+            float4 rv[16];
+            const float* rp = res + (size_t)(mb + rr) * ld + n;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) rv[p] = *reinterpret_cast<const float4*>(rp + (size_t)p * 4 * ld);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = i * 16 + l15;
+                    *reinterpret_cast<f32x4*>(slice + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4)) = acc[half * 4 + i][j];
+                }
+            float* xp = x + (size_t)(mb + rr) * ld + n;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int r = p * 4 + rr, m = mb + r;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slice + r * 256 + ((ch ^ (r & 15)) << 4));
+                const bool second = m >= m1 && b1 != b0;
+                const float4 gg = second ? g1 : g0;
+                const bool masked = (m - (second ? m1 : m0)) >= (second ? len1 : len0);
+                float4 o = rv[p];
+                const float tx = gg.x * (v[0] + bv.x), ty = gg.y * (v[1] + bv.y), tz = gg.z * (v[2] + bv.z), tw = gg.w * (v[3] + bv.w);
+                o.x = masked ? o.x : o.x + tx; o.y = masked ? o.y : o.y + ty; o.z = masked ? o.z : o.z + tz; o.w = masked ? o.w : o.w + tw;
+                *reinterpret_cast<float4*>(xp + (size_t)p * 4 * ld) = o;
+            }
+        }
+    }
 };
 
 // Fused QKV projection epilogue (modules.py:469-497): bias, interleaved-pair rotary on the first `pe_heads` heads of
@@ -184,6 +271,116 @@ template <typename TO> struct EpiQKV {
             a0 = r0; a1 = r1; a2 = r2; a3 = r3;
         }
         if (r.cs) store4(c.dst + r.base + c.hoff, a0 * c.scale, a1 * c.scale, a2 * c.scale, a3 * c.scale);
+    }
+    // Staged form.  q / k: the wave tile is ONE head (64 columns = the 128 contiguous bytes of a (batch row, head, position) row), so
+    // whether rotary applies is wave-uniform and the no-rotary heads (15 of 16 with pe_attn_head = 1) load nothing but the bias;
+    // rotary heads request the cos / sin pairs of 2 fragment rows at a time (4: the kernel spills).  V^T: staging row = head dim (64 of them, 128 positions
+    // x 2 B), out: 16 lanes x 16 B = 256 contiguous bytes of one V^T row; needs 8 aligned rows to be 8 consecutive positions of one
+    // utterance (no packing, Nseq % 8 == 0).
+    static constexpr bool kStaged = sizeof(TO) == 2;
+    __device__ __forceinline__ bool staged_ok(bool transposed) const {
+        return Nseq >= 8 && (!transposed || (rowmap == nullptr && (Nseq & 7) == 0));
+    }
+    template <int MI, int NJ>
+    __device__ __forceinline__ void staged(char* slice, int lane, int mw, int nw, const f32x4 (&acc)[MI][NJ], bool transposed) const {
+        if constexpr (sizeof(TO) == 2) {
+            static_assert(MI == 8 && NJ == 4, "128 x 64 wave tile");
+            const int l15 = lane & 15, g = lane >> 4;
+            if (transposed) {
+                float bn[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bn[j] = bias[nw + j * 16 + l15];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int r = j * 16 + l15;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const f32x4 v = acc[i][j];
+                        *reinterpret_cast<u32x2*>(slice + r * 256 + (((i * 2 + (g >> 1)) ^ (r & 15)) << 4) + ((g & 1) << 3)) =
+                            pack4<TO>(v[0] + bn[j], v[1] + bn[j], v[2] + bn[j], v[3] + bn[j]);
+                    }
+                }
+                const int rr = lane >> 4, ch = lane & 15;
+                const int m = mw + ch * 8, b = m / Nseq, pos = m - b * Nseq;
+                TO* dst = vt + (size_t)b * H * 64 * Npad + (size_t)(nw - 2 * H * 64 + rr) * Npad + pos;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int r = p * 4 + rr;
+                    *reinterpret_cast<u32x4*>(dst + (size_t)p * 4 * Npad) = *reinterpret_cast<const u32x4*>(slice + r * 256 + ((ch ^ (r & 15)) << 4));
+                }
+                return;
+            }
+            const int inner = H * 64;
+            const int which = nw >= inner ? 1 : 0, h = (nw - which * inner) >> 6;
+            const bool rot = h < pe_heads;
+            const float scale = which ? 1.0f : q_scale;
+            float4 bj[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bj[j] = *reinterpret_cast<const float4*>(bias + nw + j * 16 + g * 4);
+            auto put = [&](int i, int j, float a0, float a1, float a2, float a3) {
+                const int r = i * 16 + l15;
+                *reinterpret_cast<u32x2*>(slice + r * 128 + (((j * 2 + (g >> 1)) ^ (r & 7)) << 4) + ((g & 1) << 3)) =
+                    pack4<TO>(a0 * scale, a1 * scale, a2 * scale, a3 * scale);
+            };
+            if (rot) {
+#pragma unroll
+                for (int ih = 0; ih < 4; ++ih) {
+                    float2 cs[2][NJ], sn[2][NJ];
+#pragma unroll
+                    for (int i4 = 0; i4 < 2; ++i4) {
+                        const int m = mw + (ih * 2 + i4) * 16 + l15;
+                        int pos = m - (m / Nseq) * Nseq;
+                        if (rowmap) pos = min(rowmap[m].y, Nseq - 1);   // (alignment rows of a packed utterance: any valid table row, dropped below)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            cs[i4][j] = *reinterpret_cast<const float2*>(rope_cos + pos * 32 + ((j * 16 + g * 4) >> 1));
+                            sn[i4][j] = *reinterpret_cast<const float2*>(rope_sin + pos * 32 + ((j * 16 + g * 4) >> 1));
+                        }
+                    }
+#pragma unroll
+                    for (int i4 = 0; i4 < 2; ++i4)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const f32x4 v = acc[ih * 2 + i4][j];
+                            const float a0 = v[0] + bj[j].x, a1 = v[1] + bj[j].y, a2 = v[2] + bj[j].z, a3 = v[3] + bj[j].w;
+                            const float2 c = cs[i4][j], sv = sn[i4][j];
+                            put(ih * 2 + i4, j, a0 * c.x - a1 * sv.x, a1 * c.x + a0 * sv.x, a2 * c.y - a3 * sv.y, a3 * c.y + a2 * sv.y);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const f32x4 v = acc[i][j];
+                        put(i, j, v[0] + bj[j].x, v[1] + bj[j].y, v[2] + bj[j].z, v[3] + bj[j].w);
+                    }
+            }
+            const int rr = lane >> 3, ch = lane & 7;
+            TO* dsth = (which ? k : q) + (size_t)h * Nseq * 64 + ch * 8;
+            if (rowmap) {
+                int2 bp[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) bp[p] = rowmap[mw + p * 8 + rr];
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), visible: the guarded stores below wait for nothing
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int r = p * 8 + rr;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(slice + r * 128 + ((ch ^ (r & 7)) << 4));
+                    if (bp[p].y < Nseq) *reinterpret_cast<u32x4*>(dsth + ((size_t)bp[p].x * H * Nseq + bp[p].y) * 64) = d;
+                }
+            } else {
+                const int m = mw + rr;
+                int b = m / Nseq, pos = m - b * Nseq;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int r = p * 8 + rr;
+                    *reinterpret_cast<u32x4*>(dsth + ((size_t)b * H * Nseq + pos) * 64) = *reinterpret_cast<const u32x4*>(slice + r * 128 + ((ch ^ (r & 7)) << 4));
+                    pos += 8;
+                    if (pos >= Nseq) { pos -= Nseq; ++b; }
+                }
+            }
+        }
     }
     __device__ __forceinline__ TRowCtx trow(int m, int M) const {
         int b = m / Nseq, pos = m - b * Nseq;

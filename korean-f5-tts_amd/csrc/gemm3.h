@@ -29,6 +29,10 @@
 
 namespace f5 {
 
+// does the epilogue offer the staged (row-major through LDS) store interface of gemm.h, and in which form
+template <typename E, typename = void> struct epi_staged : std::false_type {};
+template <typename E> struct epi_staged<E, std::void_t<decltype(E::kStaged)>> : std::integral_constant<bool, E::kStaged> {};
+
 template <int OFF> __device__ __forceinline__ void lds_read_b128_off(u32x4& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
@@ -244,6 +248,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
     // front of every store (gemm2.h).
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     const bool interior = m0 + BM <= M && n0 + BN <= N;
+    // Staged stores (gemm.h): the ring is free now (every wave is past its last fragment read and no LDS-DMA is in flight), so each
+    // wave turns its 128 x 64 tile through its own 16 KiB slice -- fragment order in, rows out.  No barrier: a wave only reads what
+    // it wrote itself.
+    if constexpr (epi_staged<Epi>::value) {
+        if (interior && epi.staged_ok(transposed)) {
+            epi.template staged<MI, NJ>(smem + wave * (16 * 1024), lane, mw, nw, acc, transposed);
+            return;
+        }
+    }
     if (!transposed) {
         if (interior) {
 #pragma unroll

@@ -94,10 +94,10 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     // A many-row problem whose row count is a few rows past a multiple of 256 (UNetT: 16 x 1025 = 16,400 rows) would pay
     // a whole extra round of 256-row tiles for the last 16 rows: the 256-row multiple goes to the ping-pong kernel and the
     // remainder to one row of 64x64 tiles (same K order per element: bit-identical to a single launch).
-    // The residual epilogue (EpiGateRes) reads and writes the f32 stream: 128 MB per launch at 16,384 rows, which a single round
-    // of 256x256 tiles cannot overlap with anything; two rounds of 256x128 tiles overlap the first round's stores with the
-    // second round's K loop (C3, same box: 1,433 -> 1,408 ms).  Expressed as a per-round penalty on the ping-pong tile.
-    const float g3_pen = epilogue_streams_residual(epi) ? 6.0f : 0.0f;
+    // (Round 2 sent the residual epilogue -- EpiGateRes reads and writes the f32 stream, 268 MB per launch at 32,768 rows -- to two
+    // rounds of 256x128 tiles because the ping-pong kernel's fragment-order epilogue overlapped with nothing.  With the staged
+    // row-major epilogue (gemm.h) the ping-pong tile wins there too: tools/block_gemm_time.py, 32,768 rows, out-proj / FF2.)
+    const float g3_pen = 0.0f;
     if (K % KT == 0 && force_cfg == -1 && !m_limit && cv.tpt == 0 && !split && sizeof(T) == 2 && gemm3_epilogue_ok(epi)) {
         const int rem = M % 256, main = M - rem;
         const int cfg_main = (rem > 0 && rem <= 64 && main >= 4096) ? pick_cfg_v2(main, N, true, g3_pen) : -1;
