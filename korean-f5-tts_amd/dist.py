@@ -23,29 +23,54 @@ def utterance_cost(n_frames: int) -> float:
 MAX_BATCH_FRAMES = 16384
 
 
-def batches_of(shard: list[int], durations: list[int], batch_size: int, max_batch_frames: int = MAX_BATCH_FRAMES) -> list[list[int]]:
-    """Length-sorted batches of a shard under a FRAME budget, the reference's batching rule (utils_eval.py:146-202:
-    `infer_batch_size` counts mel frames, not utterances): a batch takes neighbours of the sorted list while
-    count x (its longest member) <= max_batch_frames and count <= batch_size.  A short last batch is evened out with
-    its predecessor (a handful of rows runs the GEMMs far below their many-row rate)."""
-    s = sorted(shard, key=lambda i: (-durations[i], i))
+# Row granules of the four block GEMMs on 256 CUs with 256 x 256 output tiles (csrc/gemm3.h): a launch runs whole ROUNDS of 256
+# tiles, so its time is that of its row count rounded up to 256 x 256 / (N / 256) rows -- QKV (N = 3072): 5,461 rows, FF1 (2048):
+# 8,192, out-proj and FF2 (1024): 16,384.  Weights = each GEMM's share of the block's GEMM flops.  Measured (round 3, bench.py
+# shard8): two batches of 11 utterances x 1,024 frames (22,528 rows with CFG: 1.4 rounds -> 2) cost as much as 16 + 16.
+_GEMM_COL_TILES = ((3.0 / 8.0, 12), (1.0 / 8.0, 4), (2.0 / 8.0, 8), (2.0 / 8.0, 4))   # (share of the flops, N / 256) of QKV, out, FF1, FF2
+
+
+def batch_cost(count: int, max_frames: int) -> float:
+    """Cost of ONE batch as it runs: `count` utterances padded to `max_frames`, CFG doubling the rows; the GEMM term is quantised to
+    whole rounds of tiles per GEMM, the attention term (per head and 128-query block: fine-grained) is not.  Same unit as
+    utterance_cost (a batch of 8 x 1,024 frames, i.e. 16,384 rows, costs 8 x utterance_cost(1024))."""
+    rows = 2 * count * max_frames
+    row_tiles = -(-rows // 256)
+    q = sum(w * (-(-row_tiles * c // 256)) * 65536.0 / c for w, c in _GEMM_COL_TILES)   # rows, rounded up to whole rounds of 256 tiles
+    return 16.0 * 1024 * q / 2 + 4.0 * count * max_frames * max_frames
+
+
+def _greedy_batches(s: list[int], durations: list[int], batch_size: int, max_batch_frames: int) -> list[list[int]]:
     out: list[list[int]] = []
     k = 0
     while k < len(s):
         cap = max(1, min(batch_size, max_batch_frames // max(durations[s[k]], 1)))
         out.append(s[k:k + cap])
         k += cap
-    if len(out) >= 2 and 2 * len(out[-1]) < len(out[-2]):
+    return out
+
+
+def batches_of(shard: list[int], durations: list[int], batch_size: int, max_batch_frames: int = MAX_BATCH_FRAMES) -> list[list[int]]:
+    """Length-sorted batches of a shard under a FRAME budget, the reference's batching rule (utils_eval.py:146-202:
+    `infer_batch_size` counts mel frames, not utterances): a batch takes neighbours of the sorted list while
+    count x (its longest member) <= max_batch_frames and count <= batch_size.  The last two batches are evened out when that is
+    cheaper under batch_cost (it usually is not: 16 + 6 utterances of 1,024 frames run 3 rounds of GEMM tiles, 11 + 11 run 4)."""
+    s = sorted(shard, key=lambda i: (-durations[i], i))
+    out = _greedy_batches(s, durations, batch_size, max_batch_frames)
+    if len(out) >= 2:
         both = out[-2] + out[-1]
         h = (len(both) + 1) // 2
-        out[-2:] = [both[:h], both[h:]]
+        even = [both[:h], both[h:]]
+        cost = lambda bs: sum(batch_cost(len(b), durations[b[0]]) for b in bs)
+        if cost(even) < cost(out[-2:]):
+            out[-2:] = even
     return out
 
 
 def padded_cost(shard: list[int], durations: list[int], batch_size: int, max_batch_frames: int = MAX_BATCH_FRAMES) -> float:
-    """Cost of a shard AS IT RUNS: every batch is padded to its longest member, and with the default
-    attn_mask_enabled=False the pad rows are computed like any other (modules.py:499-508: no key mask)."""
-    return sum(len(b) * utterance_cost(durations[b[0]]) for b in batches_of(shard, durations, batch_size, max_batch_frames))
+    """Cost of a shard AS IT RUNS: every batch is padded to its longest member -- with the default attn_mask_enabled=False the
+    pad rows are computed like any other (modules.py:499-508: no key mask) -- and its GEMMs run whole rounds of tiles."""
+    return sum(batch_cost(len(b), durations[b[0]]) for b in batches_of(shard, durations, batch_size, max_batch_frames))
 
 
 def partition(durations: list[int], world: int, batch_size: int = 32, max_batch_frames: int = MAX_BATCH_FRAMES) -> list[list[int]]:
@@ -74,7 +99,7 @@ def partition(durations: list[int], world: int, batch_size: int = 32, max_batch_
             i = best
         return slices
 
-    lo, hi = max(valid), n * max(valid)          # hi: everything in one shard, padded to the longest
+    lo, hi = 0.0, padded_cost(order, durations, batch_size, max_batch_frames)   # hi: everything in one shard
     for _ in range(32):
         mid = 0.5 * (lo + hi)
         if len(cut(mid)) <= world:

@@ -103,17 +103,24 @@ def test_partition_is_complete_contiguous_and_deterministic():
 
 def test_partition_padded_cost_is_balanced():
     """What a rank pays is the PADDED cost of its batches (attn_mask_enabled=False computes pad rows): the slowest rank
-    must stay within 10 % of an ideal split of the valid work (round 2's LPT deal: 1.51 at world 8)."""
+    must stay within 10 % of an ideal split of the valid work (round 2's LPT deal: 1.51 at world 8); with the GEMMs' whole
+    rounds of tiles counted as well (D.batch_cost, what partition() balances) within 13 %, and the ranks within 10 % of each other."""
     durs = _c4_durations()
     total_valid = sum(D.utterance_cost(d) for d in durs)
     for world in (1, 2, 4, 8):
         shards = D.partition(durs, world)
-        worst = max(D.padded_cost(s, durs, 32) for s in shards)
-        assert worst <= 1.10 * total_valid / world, (world, worst / (total_valid / world))
+        padded = [sum(len(b) * D.utterance_cost(durs[b[0]]) for b in D.batches_of(s, durs, 32)) for s in shards]
+        assert max(padded) <= 1.10 * total_valid / world, (world, max(padded) / (total_valid / world))
+        quant = [D.padded_cost(s, durs, 32) for s in shards]
+        assert max(quant) <= 1.13 * total_valid / world, (world, max(quant) / (total_valid / world))
+        assert min(quant) >= 0.90 * max(quant), (world, min(quant) / max(quant))
         # per batch: padded frames / valid frames
         for s in shards:
             for b in D.batches_of(s, durs, 32):
                 assert len(b) * durs[b[0]] <= 1.12 * sum(durs[i] for i in b)
+    # the unit of batch_cost: one full round of tiles = 8 utterances x 1,024 frames with CFG
+    assert D.batch_cost(8, 1024) == 8 * D.utterance_cost(1024)
+    assert D.batch_cost(11, 1024) > 11 * D.utterance_cost(1024) * 1.15      # 22,528 rows: 1.4 rounds of the N = 1024 GEMMs run as 2
 
 
 def test_partition_edge_cases():
