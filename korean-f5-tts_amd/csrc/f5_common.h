@@ -26,10 +26,12 @@ namespace f5 {
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // torch: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-    // 0.5 (1 + tanh u) == sigmoid(2u) == 1 / (1 + exp(-2u)): one v_exp + one v_rcp instead of a tanhf expansion
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    return x * __frcp_rn(1.0f + __expf(-2.0f * u));
+    // 0.5 (1 + tanh u) == sigmoid(2u) == 1 / (1 + 2^(-2 u log2 e)): ONE bare v_exp_f32 and one v_rcp_f32 (1 ulp each).  __expf() is
+    // v_exp_f32 wrapped in a range reduction with an exec-masked branch: ~18 instructions per element, and at 128 elements per lane
+    // the GELU epilogue of the FF1 projection was VALU-bound (csrc/gemm.h EpiStore::staged).  An overflowing 2^(..) gives x * 0.
+    const float c0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, c1 = c0 * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(c1, x * x, c0));
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

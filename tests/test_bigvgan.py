@@ -53,8 +53,11 @@ def test_slaney_filterbank_and_bigvgan_mel_shape():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
-@pytest.mark.parametrize("cfg_name,T,B", [("BIGVGAN_TINY", 37, 2), ("BIGVGAN_TINY", 5, 1), ("BIGVGAN_MID", 24, 1)])
+@pytest.mark.parametrize("cfg_name,T,B", [("BIGVGAN_TINY", 37, 2), ("BIGVGAN_TINY", 5, 1), ("BIGVGAN_MID", 24, 1), ("BIGVGAN_V2_24K", 8, 1)])
 def test_bigvgan_hip_vs_oracle(cfg_name, T, B, prec):
+    """(BIGVGAN_V2_24K, T = 8: the PRODUCTION width -- 1536 / 768 / 384 / 192 / 96 channels through the implicit-GEMM kernels with
+    tpt = C / 32 up to 48 K-tiles per tap, and in f16x3 the pre-split MODE 5 operands + the hardware-sin activation -- on 8 frames,
+    which the CPU restatement finishes in seconds.  Still PARITY UNPINNED: the checker is this repository's restatement.)"""
     cfg = getattr(P.config, cfg_name, None) or dict(P.config.BIGVGAN_V2_24K, upsample_initial_channel=256)   # MID: all 6 stages, 256 -> 4 channels
     V = P.weights.synthetic_state_dict(P.weights.bigvgan_param_shapes(cfg), seed=3)
     mel = torch.randn(B, T, 100, generator=torch.Generator().manual_seed(T)).permute(0, 2, 1)   # the callers' transposed view

@@ -25,6 +25,8 @@ DEV = "cuda:0"
 TOL_PARITY = 1e-3                       # north_star: mel L-inf of the parity precision against the reference CPU path
 # 16-bit operand precisions at C2 size (NFE = 16, state magnitude ~5): about twice the measured L-inf against the oracle
 TOL_C2 = {"bf16": 6e-2, "f16": 8e-3}
+# the same for C5's backbone (UNetT Base, ONE Euler step of size 1: measured bf16 5.7e-2, f16 7.3e-3 .. 8.6e-3, f16p 5.0e-3)
+TOL_C5 = {"bf16": 1.1e-1, "f16": 1.6e-2, "f16p": 1.0e-2}
 NV = P.config.VOCAB_SIZE + 1            # load_model: text_num_embeds = vocab_size + 1 (utils_infer.py:313-317)
 
 
@@ -204,4 +206,4 @@ def test_c5_base_unett_batch_vs_oracle():
         print(f"[C5 UNetT Base] {prec} traj Linf {e16:.3e}")
         # (f16p on UNetT: without AdaLN the 24 blocks' own f16 products dominate -- 4.8e-3 here against 7.3e-3 for f16; the parity
         #  precision of this backbone is f16x3)
-        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C2["f16"] if prec == "f16p" else TOL_C2[prec])
+        assert e16 < (TOL_PARITY if prec == "f16x3" else TOL_C5[prec])
