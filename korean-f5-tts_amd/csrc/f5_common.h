@@ -54,10 +54,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// f32 -> f16 must be a conversion of the ROUNDED f32 value.  Left to itself hipcc folds a multiply (or multiply-add) that feeds the
+// conversion into v_fma_mixlo_f16 -- the product rounded ONCE, straight to f16 -- in some instantiations of an epilogue and not in
+// others: two tile shapes then disagree in the last f16 bit of a few elements (tools/cfg_dep.py f16: 6e-4 after two layers), the
+// same defect -ffp-contract=off removes for f32.  Vector stores convert PAIRS (v_cvt_pk_f16_f32: a plain conversion, nothing to
+// fold into); the scalar form passes the value through an empty asm (opaque at the conversion, emits nothing).  An asm barrier
+// on every element of the vector stores made hipcc wait for each group of three loads in the LayerNorm kernel (different register
+// allocation -> write-after-write waits): 34 -> 51 us per launch at 32,768 rows.
+__device__ __forceinline__ float f16_src(float v) {
+    asm("" : "+v"(v));
+    return v;
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2_cv;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
+__device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{a, b}, f16x2_cv));
+}
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
-template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)f16_src(v); }
 
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -67,8 +83,7 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
     *reinterpret_cast<bf16x4*>(p) = v;
 }
 __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
-    f16x4 v = {(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
-    *reinterpret_cast<f16x4*>(p) = v;
+    *reinterpret_cast<u32x2*>(p) = u32x2{cvt2_f16(a, b), cvt2_f16(c, d)};
 }
 
 // four f32 -> 8 bytes of 16-bit type TO (the value store4 would write)
@@ -78,8 +93,7 @@ template <> __device__ __forceinline__ u32x2 pack4<bf16_t>(float a, float b, flo
     return __builtin_bit_cast(u32x2, v);
 }
 template <> __device__ __forceinline__ u32x2 pack4<f16_t>(float a, float b, float c, float d) {
-    f16x4 v = {(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
-    return __builtin_bit_cast(u32x2, v);
+    return u32x2{cvt2_f16(a, b), cvt2_f16(c, d)};
 }
 
 // ---- F5_PREC_F16X3 helpers: x = hi + lo with hi = f16(x), lo = f16(x - hi) (gemm2.h MODE 3, attn.h) ----
@@ -120,8 +134,7 @@ template <> __device__ __forceinline__ u32x4 pack8<bf16_t>(float a0, float a1, f
     return __builtin_bit_cast(u32x4, v);
 }
 template <> __device__ __forceinline__ u32x4 pack8<f16_t>(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-    f16x8 v = {(f16_t)a0, (f16_t)a1, (f16_t)a2, (f16_t)a3, (f16_t)a4, (f16_t)a5, (f16_t)a6, (f16_t)a7};
-    return __builtin_bit_cast(u32x4, v);
+    return u32x4{cvt2_f16(a0, a1), cvt2_f16(a2, a3), cvt2_f16(a4, a5), cvt2_f16(a6, a7)};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

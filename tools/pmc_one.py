@@ -8,7 +8,7 @@ could not say where.  This script is the minimum that dispatches every per-block
 (F5_HIP_GRAPH=0: the first call of a signature is eager anyway), no warm-up, no vocoder, ~2.7k dispatches for c2 and ~1.4k for
 c3chunk, and it says on stderr where it is, so a stalled log names the phase.
 
-Workloads (F5-TTS Base, bf16 unless F5_PMC_PREC is set, synthetic weights seed 0):
+Workloads (F5-TTS Base, f16p -- bench.py's precision -- unless F5_PMC_PREC is set, synthetic weights seed 0):
   c2       B=1, 256 + 768 frames, NFE=16, cfg 2                    (2,048 rows per backbone call: the latency-bound GEMM shapes)
   c3chunk  B=16 x 1024 frames, NFE=4, cfg 2  = ONE 32,768-row chunk (the many-row kernels: gemm_pp_kernel, attn2 at 16 x 2 x 16 heads)
 """
@@ -36,7 +36,7 @@ torch.set_num_threads(1)
 import f5_tts_amd as P  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
-prec = os.environ.get("F5_PMC_PREC", "bf16")
+prec = os.environ.get("F5_PMC_PREC", "f16p")
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 torch.zeros(1, device=dev)

@@ -107,7 +107,7 @@ print("\n".join(lines))
 # ---- DiT-block GEMM class: the kernels launched once per block per step (>= 22 x NFE launches each)
 M = 2048 if wl == "c2" else 32768
 nfe = 16 if wl == "c2" else 4
-D, F, e = 1024, 2048, 2          # bf16 operands
+D, F, e = 1024, 2048, 2          # 16-bit operands
 alg = {"qkv": M * D * e + 3 * D * D * e + 3 * M * D * e, "out": M * D * e + D * D * e + 2 * M * D * 4,
        "ff1": M * D * e + F * D * e + M * F * e, "ff2": M * F * e + D * F * e + 2 * M * D * 4}
 alg_avg = sum(alg.values()) / 4

@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 "$@" > "$root/gpurun_out/prof_$tag.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-precisions --no-c4 --no-c3 "$@" > "$root/gpurun_out/prof_$tag.log" 2>&1
 rc=$?
 cd "$root"
 f=$(ls $out/*/*kernel_stats.csv 2>/dev/null | head -n 1)
