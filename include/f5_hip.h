@@ -45,6 +45,10 @@ extern "C" {
                             entering and of the flow prediction leaving the backbone is what dominates F5_PREC_F16's error (DESIGN.md
                             section 3, tools/x3_ablate.py); meets the 1e-3 parity bar at ~F5_PREC_F16 speed */
 
+#define F5_OPT_QK_RMSNORM 1        /* qk_norm="rms_norm" (modules.py:397-404,481-484): weights ...attn.q_norm.weight / k_norm.weight [64] */
+#define F5_OPT_LONG_SKIP 2         /* long_skip_connection=True (dit.py:205,313-324): long_skip_connection.weight [D, 2D] */
+#define F5_OPT_TEXT_AVG_UPSAMPLE 4 /* text_embedding_average_upsampling=True (dit.py:54-84; needs text_mask_padding) */
+
 #define F5_BACKBONE_DIT 0
 #define F5_BACKBONE_UNETT 1
 
@@ -69,7 +73,8 @@ typedef struct f5_config {
     int32_t text_num_embeds;   /* constructor argument; the table has text_num_embeds + 1 rows */
     int32_t mel_dim;           /* 100 */
     int32_t max_pos;           /* rows of the rotary table given as aux.rope_cos/sin (>= longest sequence) */
-    int32_t reserved[5];
+    int32_t options;           /* F5_OPT_* bits: the DiT constructor options no shipped config switches on */
+    int32_t reserved[4];
 } f5_config;
 
 const char* f5_last_error(void);

@@ -8,6 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libf5hip.so")
 
+F5_OPT_QK_RMSNORM, F5_OPT_LONG_SKIP, F5_OPT_TEXT_AVG_UPSAMPLE = 1, 2, 4
 F5_PREC_F32, F5_PREC_BF16, F5_PREC_F16, F5_PREC_F16X3, F5_PREC_F16P = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": F5_PREC_F32, "fp32": F5_PREC_F32, "bf16": F5_PREC_BF16, "f16": F5_PREC_F16, "fp16": F5_PREC_F16,
               "f16x3": F5_PREC_F16X3, "f16p": F5_PREC_F16P, "parity": F5_PREC_F16P}
@@ -23,8 +24,8 @@ class F5Error(RuntimeError):
 class f5_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "backbone", "precision", "dim", "depth", "heads", "dim_head", "ff_dim", "text_dim", "conv_layers",
-        "pe_attn_head", "text_mask_padding", "attn_mask_enabled", "text_num_embeds", "mel_dim", "max_pos")] + \
-        [("reserved", C.c_int32 * 5)]
+        "pe_attn_head", "text_mask_padding", "attn_mask_enabled", "text_num_embeds", "mel_dim", "max_pos", "options")] + \
+        [("reserved", C.c_int32 * 4)]
 
 
 class f5_bigvgan_config(C.Structure):

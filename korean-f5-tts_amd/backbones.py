@@ -20,10 +20,6 @@ class _HipBackbone(nn.Module):
         arch.pop("dropout", None)
         arch.pop("attn_backend", None)          # one attention implementation: the gfx950 flash kernel
         arch.pop("checkpoint_activations", None)
-        if arch.pop("long_skip_connection", False):
-            raise NotImplementedError("long_skip_connection is unused by every shipped config")
-        if arch.pop("text_embedding_average_upsampling", False):
-            raise NotImplementedError("text_embedding_average_upsampling is unused by every shipped config")
         self.arch = normalize_arch(arch, mel_dim)
         self.dim = self.arch["dim"]
         self.depth = self.arch["depth"]

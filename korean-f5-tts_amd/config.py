@@ -46,5 +46,7 @@ def normalize_arch(arch: dict, mel_dim: int = MEL_DIM) -> dict:
     a.setdefault("pe_attn_head", None)
     a.setdefault("attn_mask_enabled", False)
     a.setdefault("qk_norm", None)
+    a.setdefault("long_skip_connection", False)                  # dit.py:166,205 (DiT only)
+    a.setdefault("text_embedding_average_upsampling", False)     # dit.py:160,39-42 (DiT only)
     a["mel_dim"] = mel_dim
     return a

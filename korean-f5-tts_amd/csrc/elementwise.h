@@ -429,6 +429,75 @@ static __global__ void zero_tail_rows_kernel(float* __restrict__ h, int B, int N
     }
 }
 
+// zipvoice-style late average upsampling of the text embedding (dit.py:54-84; text_embedding_average_upsampling=True): the VALID
+// tokens of a sample (original id != filler, position < the sample's own length) are repeated to fill its audio length, the
+// last `remainder` tokens once more than the others; rows past the length and samples without a valid token are zero.
+// One workgroup per sample; `in` -> `out` (different buffers).
+static __global__ __launch_bounds__(256) void text_avg_upsample_kernel(const long long* __restrict__ text, int nt, const float* __restrict__ in,
+                                                                        float* __restrict__ out, int N, int Dt, const int* __restrict__ lens) {
+    extern __shared__ int valid_idx[];                    // [N]: positions of the valid tokens, in order
+    __shared__ int n_valid;
+    const int b = blockIdx.x;
+    const int alen = lens ? min(lens[b], N) : N;
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int n = 0; n < alen && n < nt; ++n)
+            if (text[(size_t)b * nt + n] + 1 != 0) valid_idx[c++] = n;
+        n_valid = c;
+    }
+    __syncthreads();
+    const int tl = n_valid, d4 = Dt / 4;
+    const int base = tl > 0 ? alen / tl : 0, rem = tl > 0 ? alen % tl : 0;
+    const int split = (tl - rem) * base;                  // output rows fed by the tokens that repeat `base` times
+    for (long idx = threadIdx.x; idx < (long)N * d4; idx += blockDim.x) {
+        const int n = (int)(idx / d4), c = (int)(idx % d4);
+        float4 v = make_float4(0, 0, 0, 0);
+        if (n < alen && tl > 0) {
+            const int j = n < split ? n / base : (tl - rem) + (n - split) / (base + 1);
+            v = reinterpret_cast<const float4*>(in + ((size_t)b * N + valid_idx[j]) * Dt)[c];
+        }
+        reinterpret_cast<float4*>(out + ((size_t)b * N + n) * Dt)[c] = v;
+    }
+}
+
+// qk_norm = "rms_norm" (modules.py:397-404,481-497): q and k, as the QKV epilogue left them WITHOUT rotary and scale
+// ([Bp, H, N, 64] each), get RMSNorm(64, eps) with their own gain, then the rotary embedding on the first pe_heads heads, then q its
+// softmax scale -- in place.  16 lanes per (batch row, head, position): 4 consecutive dims per lane = two rotary pairs.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* __restrict__ k, const float* __restrict__ gq,
+                                                          const float* __restrict__ gk, const float* __restrict__ rope_cos,
+                                                          const float* __restrict__ rope_sin, long rows, int N, int H, int pe_heads,
+                                                          float q_scale, float eps) {
+    const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long r = gid >> 4;                              // (b * H + h) * N + pos
+    if (r >= rows) return;
+    const int d = (int)(gid & 15) * 4;
+    const int pos = (int)(r % N), h = (int)((r / N) % H);
+    float2 cs = make_float2(1, 1), sn = make_float2(0, 0);
+    const bool rot = h < pe_heads;
+    if (rot) {
+        cs = *reinterpret_cast<const float2*>(rope_cos + (size_t)pos * 32 + (d >> 1));
+        sn = *reinterpret_cast<const float2*>(rope_sin + (size_t)pos * 32 + (d >> 1));
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        T* p = (which ? k : q) + r * 64 + d;
+        const float4 g = *reinterpret_cast<const float4*>((which ? gk : gq) + d);
+        float a0 = to_f32(p[0]), a1 = to_f32(p[1]), a2 = to_f32(p[2]), a3 = to_f32(p[3]);
+        float ss = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        const float rs = rsqrtf(ss * (1.0f / 64.0f) + eps);
+        a0 = a0 * rs * g.x; a1 = a1 * rs * g.y; a2 = a2 * rs * g.z; a3 = a3 * rs * g.w;
+        if (rot) {
+            const float r0 = a0 * cs.x - a1 * sn.x, r1 = a1 * cs.x + a0 * sn.x;
+            const float r2 = a2 * cs.y - a3 * sn.y, r3 = a3 * cs.y + a2 * sn.y;
+            a0 = r0; a1 = r1; a2 = r2; a3 = r3;
+        }
+        const float sc = which ? 1.0f : q_scale;
+        store4(p, a0 * sc, a1 * sc, a2 * sc, a3 * sc);
+    }
+}
+
 // --------------------------------------------------------------------------------------- weight repacking
 // Conv1d weight [R = out channels][A = in channels per group][31 taps] (torch) -> implicit-GEMM operand
 // out[r][tap * A + a], rows zero-padded to ld_out (a whole number of 128-byte K-tiles, convpos.h)

@@ -53,6 +53,10 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     if (c->backbone != F5_BACKBONE_DIT && c->backbone != F5_BACKBONE_UNETT) return fail(F5_EINVAL, "bad backbone");
     if (c->backbone == F5_BACKBONE_UNETT && (c->depth % 2)) return fail(F5_EINVAL, "UNetT depth must be even");
     if (c->text_dim > 2048 || c->dim > 2048) return fail(F5_EINVAL, "dims > 2048 unsupported");
+    if (c->options & ~(F5_OPT_QK_RMSNORM | F5_OPT_LONG_SKIP | F5_OPT_TEXT_AVG_UPSAMPLE)) return fail(F5_EINVAL, "unknown option bits %d", c->options);
+    if (c->options && c->backbone != F5_BACKBONE_DIT) return fail(F5_EINVAL, "F5_OPT_* are options of the DiT backbone (dit.py:160-166)");
+    if ((c->options & F5_OPT_TEXT_AVG_UPSAMPLE) && !c->text_mask_padding)
+        return fail(F5_EINVAL, "text_embedding_average_upsampling requires text_mask_padding to be True (dit.py:41-42)");
     f5_engine* e = new f5_engine();
     e->cfg = *c;
     e->inner = c->heads * 64;

@@ -183,6 +183,10 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
             if (e->x3_ablate & 32) zlo(b.ff2);
             HIPCHK(hipGetLastError());
         }
+        if (c.options & F5_OPT_QK_RMSNORM) {
+            CHK(copy_vec(e, s, at + ".q_norm.weight", {64}, &b.qn));
+            CHK(copy_vec(e, s, at + ".k_norm.weight", {64}, &b.kn));
+        }
         if (dit) {
             modp.push_back(p + ".attn_norm.linear");
         } else {
@@ -219,6 +223,10 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         CHK(copy_vec(e, s, "norm_out.g", {D}, &P.norm_out_g));
     }
     CHK(pack_linear_bb<T>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out));
+    if (c.options & F5_OPT_LONG_SKIP) {
+        CHK(pack_linear_bb<T>(e, s, "long_skip_connection.weight", "", D, 2 * D, &P.long_skip));
+        if (e->io_split) CHK((pack_linear<float, true>(e, s, "long_skip_connection.weight", "", D, 2 * D, &P.long_skip_f)));
+    }
     if (e->io_split) {   // F5_PREC_F16P: the input / output layers once more, as split-planar f32 operands
         CHK((pack_linear<float, true>(e, s, "input_embed.proj.weight", "input_embed.proj.bias", D, e->kin, &P.in_proj_f)));
         CHK((pack_linear<float, true>(e, s, "proj_out.weight", "proj_out.bias", mel, D, &P.proj_out_f)));
@@ -285,6 +293,7 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.cat2 = nullptr;
     w.skips = nullptr;
     w.pred_all = nullptr;
+    if (c.options & F5_OPT_LONG_SKIP) w.cat2 = a.take<T>(rows * 2 * D * (e->io_split ? sizeof(float) / sizeof(T) : 1));
     if (c.backbone == F5_BACKBONE_UNETT) {
         w.cat2 = a.take<T>(rows * 2 * D * (e->io_split ? sizeof(float) / sizeof(T) : 1));   // (F5_PREC_F16P: f32 rows)
         w.skips = a.take<float>(rows * D * (c.depth / 2));
@@ -369,6 +378,12 @@ static int run_text_embed(f5_engine* e, Work<T>& w, const int64_t* text, int B, 
         hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(ew_blocks(rows * Dt / 4)), dim3(256), 0, s, out, B, N, Dt, lens_dev);
         KCHK();
     }
+    if (c.options & F5_OPT_TEXT_AVG_UPSAMPLE) {   // dit.py:112-113: after the text blocks; the mask is that of the ORIGINAL ids
+        hipLaunchKernelGGL(text_avg_upsample_kernel, dim3(B), dim3(256), (size_t)N * sizeof(int), s, (const long long*)text, nt, out, w.tx_b, N, Dt,
+                           lens_dev);
+        KCHK();
+        HIPCHK(hipMemcpyAsync(out, w.tx_b, (size_t)rows * Dt * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     e->prof.end(s);
     return F5_OK;
 }
@@ -439,6 +454,10 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
     HIPCHK(launch_convpos<T>(s, w.c1, P.conv_w[1], P.conv_kp, P.conv_b[1], w.h, w.x, Bp, N, D, lens_dev, B, pk.row_start, conv_split(e)));
     pr.end(s);
     }
+    const bool long_skip = (c.options & F5_OPT_LONG_SKIP) != 0;
+    if (long_skip)   // residual = x (dit.py:313-314); h is free once the conv embedding has used it as its own residual
+        HIPCHK(hipMemcpyAsync(w.h, w.x, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const bool qk_norm = (c.options & F5_OPT_QK_RMSNORM) != 0;
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;
     const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh are written pre-split (the A operands of the block GEMMs)
@@ -465,9 +484,18 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, pe_heads, attention_q_scale<T>(), pk.rowmap},
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, qk_norm ? 0 : pe_heads,
+                                        qk_norm ? 1.0f : attention_q_scale<T>(), pk.rowmap},
                               -1, ml, mh, pl));
         pr.end(s);
+        if (qk_norm) {   // RMSNorm on q / k comes BEFORE the rotary embedding (modules.py:481-497): the epilogue left both raw
+            const long qrows = (long)Bp * H * N;
+            pr.begin(PC_MISC, s);
+            hipLaunchKernelGGL((qknorm_rope_kernel<T>), dim3((unsigned)((qrows * 16 + 255) / 256)), dim3(256), 0, s, w.q, w.k, bw.qn, bw.kn,
+                               P.rope_cos, P.rope_sin, qrows, N, H, pe_heads, attention_q_scale<T>(), 1e-6f);
+            KCHK();
+            pr.end(s);
+        }
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl,
                                     (e->x3_ablate >> 1) & 3));
@@ -492,6 +520,26 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         pr.begin(PC_GEMM, s, gflops(D, F));
         HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F,
                               EpiGateRes{w.x, w.x, D, bw.ff2.b, m + 5 * D, mod_stride, N, nullptr}, -1, ml, mh, pl));
+        pr.end(s);
+    }
+    if (long_skip) {   // x = long_skip_connection(cat((x, residual), dim=-1))   (dit.py:323-324)
+        pr.begin(PC_MISC, s);
+        if (e->io_split) {
+            float* cat_f = reinterpret_cast<float*>(w.cat2);
+            hipLaunchKernelGGL((cat2_kernel<float>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, w.h, cat_f, (long)rows, D);
+            KCHK();
+            pr.end(s);
+            pr.begin(PC_GEMM, s, gflops(D, 2 * D));
+            HIPCHK(launch_gemm<float>(s, cat_f, 2 * D, P.long_skip_f.w, P.long_skip_f.ldw, rows, D, 2 * D,
+                                      EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}, -1, ml, mh, GemmConv{}, 1));
+        } else {
+            hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, w.h, w.cat2, (long)rows, D);
+            KCHK();
+            pr.end(s);
+            pr.begin(PC_GEMM, s, gflops(D, 2 * D));
+            HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, P.long_skip.w, P.long_skip.ldw, rows, D, 2 * D, EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE},
+                            -1, ml, mh));
+        }
         pr.end(s);
     }
     const float* mf = mod_row + (size_t)c.depth * 6 * D;  // (scale, shift)
@@ -777,7 +825,7 @@ template <typename T> static Work<T> second_half(const f5_engine* e, const Work<
 // and N -- unless text_mask_padding zeroes the rows whose ORIGINAL token is the filler (dit.py:90-91,104-108: the mask is
 // taken before drop_text), which makes it a function of the call's text: no cache then.
 static bool uc_cacheable(const f5_engine* e, int B, bool has_lens) {
-    return B == 1 && !has_lens && !(e->cfg.text_mask_padding && e->cfg.conv_layers > 0);
+    return B == 1 && !has_lens && !(e->cfg.text_mask_padding && e->cfg.conv_layers > 0) && !(e->cfg.options & F5_OPT_TEXT_AVG_UPSAMPLE);
 }
 
 // the stream-ordered body of sample(): everything between "inputs are in the arena" and "outputs are in the arena"

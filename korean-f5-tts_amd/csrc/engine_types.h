@@ -147,6 +147,7 @@ template <typename T> struct BlockW {
     LinW<float> skip_f;                // F5_PREC_F16P: the concat projection reads the RAW residual stream: split-planar f32 copy
     float* norm1_g = nullptr;          // UNetT RMSNorm gains
     float* norm2_g = nullptr;
+    float *qn = nullptr, *kn = nullptr;   // F5_OPT_QK_RMSNORM: gains of the RMSNorm on q / k [64]
 };
 
 struct TextBlockW {
@@ -164,6 +165,8 @@ template <typename T> struct Packed {
     int conv_kp = 0;
     std::vector<BlockW<T>> blocks;
     LinW<T> proj_out;
+    LinW<T> long_skip;             // F5_OPT_LONG_SKIP: Linear(2 D -> D, no bias) over [x | residual] (dit.py:205,323-324)
+    LinW<float> long_skip_f;       // ... and its split-planar f32 copy for F5_PREC_F16P (the operand is the raw stream)
     // F5_PREC_F16P: split-planar f32 copies of the input / output layers' weights (gemm2.h MODE 3 / 5, convpos.h SPLIT)
     LinW<float> in_proj_f, proj_out_f;
     float* conv_w_f[2] = {nullptr, nullptr};

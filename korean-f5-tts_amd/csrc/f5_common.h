@@ -70,6 +70,9 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_cv;
 __device__ __forceinline__ unsigned cvt2_f16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cv{a, b}, f16x2_cv));
 }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }

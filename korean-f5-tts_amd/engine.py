@@ -78,8 +78,14 @@ class Engine:
         cfg.text_mask_padding = int(bool(a["text_mask_padding"]))
         cfg.attn_mask_enabled = int(bool(a["attn_mask_enabled"]))
         cfg.text_num_embeds, cfg.mel_dim, cfg.max_pos = text_num_embeds, mel_dim, max_pos
-        if a.get("qk_norm") is not None:
-            raise _lib.F5Error("qk_norm is not supported (null in every shipped config)")
+        if a.get("qk_norm") not in (None, "rms_norm"):
+            raise ValueError(f"Unimplemented qk_norm: {a['qk_norm']}")                       # modules.py:404
+        if (a.get("qk_norm") or a.get("long_skip_connection") or a.get("text_embedding_average_upsampling")) and backbone != "DiT":
+            raise _lib.F5Error("qk_norm / long_skip_connection / text_embedding_average_upsampling are DiT options")
+        if a.get("text_embedding_average_upsampling") and not a["text_mask_padding"]:
+            raise AssertionError("text_embedding_average_upsampling requires text_mask_padding to be True")   # dit.py:41-42
+        cfg.options = ((_lib.F5_OPT_QK_RMSNORM if a.get("qk_norm") else 0) | (_lib.F5_OPT_LONG_SKIP if a.get("long_skip_connection") else 0) |
+                       (_lib.F5_OPT_TEXT_AVG_UPSAMPLE if a.get("text_embedding_average_upsampling") else 0))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.f5_create(C.byref(cfg), C.byref(self._h)), "f5_create")

@@ -52,12 +52,17 @@ def dit_param_shapes(arch: dict, text_num_embeds: int, mel_dim: int = 100) -> di
         for n in ("to_q", "to_k", "to_v"):
             s[f"{p}.attn.{n}.weight"] = (inner, D)
             s[f"{p}.attn.{n}.bias"] = (inner,)
+        if a.get("qk_norm") is not None:                         # modules.py:397-404: RMSNorm(dim_head) on q and k
+            s[p + ".attn.q_norm.weight"] = (a["dim_head"],)
+            s[p + ".attn.k_norm.weight"] = (a["dim_head"],)
         s[p + ".attn.to_out.0.weight"] = (D, inner)
         s[p + ".attn.to_out.0.bias"] = (D,)
         s[p + ".ff.ff.0.0.weight"] = (F, D)
         s[p + ".ff.ff.0.0.bias"] = (F,)
         s[p + ".ff.ff.2.weight"] = (D, F)
         s[p + ".ff.ff.2.bias"] = (D,)
+    if a.get("long_skip_connection"):                            # dit.py:205: nn.Linear(dim * 2, dim, bias=False)
+        s["long_skip_connection.weight"] = (D, 2 * D)
     s["norm_out.linear.weight"] = (2 * D, D)
     s["norm_out.linear.bias"] = (2 * D,)
     s["proj_out.weight"] = (mel_dim, D)
@@ -167,7 +172,7 @@ def _std_for(name: str, shape: tuple, std: float) -> tuple[float, float]:
             return 0.0, gain * float(fan) ** -0.5
         return 0.0, std
     if name.endswith(".norm.weight") or name.endswith("final_layer_norm.weight") or name.endswith(".g") \
-            or name == "backbone.norm.weight":
+            or name == "backbone.norm.weight" or name.endswith(("q_norm.weight", "k_norm.weight")):
         return 1.0, 0.05
     if name.endswith(".gamma") and len(shape) == 1:  # vocos layer-scale
         return 0.125, 0.02

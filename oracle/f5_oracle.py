@@ -147,8 +147,28 @@ def text_embed(W, cfg, text: torch.Tensor, seq_len: int, drop_text=False) -> tor
             h = convnext_v2_block(W, f"{pfx}.text_blocks.{i}", h)
             if mask_padding:
                 h = h.masked_fill(pad.unsqueeze(-1), 0.0)
-    assert not cfg.get("text_embedding_average_upsampling", False), "unused by every shipped config"
+    if cfg.get("text_embedding_average_upsampling", False):
+        assert mask_padding, "text_embedding_average_upsampling requires text_mask_padding to be True"   # dit.py:41-42
+        h = average_upsample_text_by_mask(h, ~pad)
     return h
+
+
+def average_upsample_text_by_mask(text: torch.Tensor, text_mask: torch.Tensor) -> torch.Tensor:
+    """dit.py:54-84 (zipvoice-style late upsampling): the valid tokens of every sample are repeated to fill the audio length,
+    the LAST `remainder` tokens once more than the others; a sample without valid tokens stays zero."""
+    b, audio_len, _ = text.shape
+    out = torch.zeros_like(text)
+    for i in range(b):
+        valid = torch.where(text_mask[i])[0]
+        tl = int(valid.numel())
+        if tl == 0:
+            continue
+        base, rem = audio_len // tl, audio_len % tl
+        idx = []
+        for j in range(tl):
+            idx.extend([j] * (base + (1 if j >= tl - rem else 0)))
+        out[i, :audio_len] = text[i, valid][torch.tensor(idx[:audio_len], dtype=torch.long)]
+    return out
 
 
 def text_embed_batch(W, cfg, text, seq_len, mask, drop_text):
@@ -211,7 +231,11 @@ def attention(W, cfg, pfx, x, mask, freqs):
     q = linear(x, W, pfx + ".to_q").view(b, n, H, dh).transpose(1, 2)
     k = linear(x, W, pfx + ".to_k").view(b, n, H, dh).transpose(1, 2)
     v = linear(x, W, pfx + ".to_v").view(b, n, H, dh).transpose(1, 2)
-    assert cfg.get("qk_norm") is None, "qk_norm is null in every shipped config"
+    qk_norm = cfg.get("qk_norm")
+    if qk_norm is not None:   # modules.py:397-404,481-484 (RMSNorm over dim_head, eps 1e-6, before the rotary embedding)
+        assert qk_norm == "rms_norm", f"Unimplemented qk_norm: {qk_norm}"
+        q = F.rms_norm(q, (dh,), weight=W[pfx + ".q_norm.weight"], eps=1e-6)
+        k = F.rms_norm(k, (dh,), weight=W[pfx + ".k_norm.weight"], eps=1e-6)
     pn = cfg.get("pe_attn_head")
     if pn is None:
         q, k = rotary_apply(q, freqs), rotary_apply(k, freqs)
@@ -292,11 +316,13 @@ def dit_forward(W, cfg, x, cond, text, time, mask=None, drop_audio_cond=False, d
         taps["time_embed"] = t
         taps["input_embed"] = h
     freqs = rotary_freqs(n, cfg.get("dim_head", 64))
-    assert not cfg.get("long_skip_connection", False), "unused by every shipped config"
+    residual = h if cfg.get("long_skip_connection", False) else None      # dit.py:313-314
     for i in range(cfg["depth"]):
         h = dit_block(W, cfg, i, h, t, mask, freqs)
         if taps is not None:
             taps[f"block{i}"] = h
+    if residual is not None:                                              # dit.py:323-324 (Linear(2 dim -> dim), no bias)
+        h = F.linear(torch.cat((h, residual), dim=-1), W["long_skip_connection.weight"])
     return final_layer(W, h, t)
 
 

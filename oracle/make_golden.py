@@ -194,6 +194,12 @@ def main():
     sample_case("sample_b1_norefaudio", tiny, B=1, cond_len=20, nt=12, duration=48, steps=5, no_ref_audio=True)
     sample_case("sample_b2_v1arch", tiny_v1, B=2, cond_len=20, nt=12, duration=[50, 33], lens=[20, 11], steps=7,
                 text_pad=[12, 7])
+    # the three DiT options no shipped config switches on (dit.py:160-161,166): RMSNorm on q / k, the long skip connection and the
+    # zipvoice-style average upsampling of the text embedding (which needs text_mask_padding)
+    tiny_opts = dict(tiny_v1, qk_norm="rms_norm", long_skip_connection=True, text_embedding_average_upsampling=True)
+    sample_case("sample_b2_options", tiny_opts, B=2, cond_len=20, nt=12, duration=[50, 33], lens=[20, 11], steps=6,
+                text_pad=[12, 7])
+    sample_case("sample_b1_options_pe1", dict(tiny_opts, pe_attn_head=1), B=1, cond_len=16, nt=9, duration=41, steps=5)
     sample_case("sample_b1_nocfg_linspace", tiny, B=1, cond_len=16, nt=8, duration=40, steps=8, cfg_strength=0.0,
                 sway=None, use_epss=False)
     sample_case("sample_b1_textclamp", tiny, B=1, cond_len=10, nt=30, duration=12, steps=5)  # duration raised to nt+1

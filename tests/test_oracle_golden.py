@@ -9,7 +9,7 @@ from oracle import f5_oracle as O
 TOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order only
 
 SAMPLE_CASES = ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_b1_editmask",
-                "sample_b1_norefaudio", "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp",
+                "sample_b1_norefaudio", "sample_b2_v1arch", "sample_b2_options", "sample_b1_options_pe1", "sample_b1_nocfg_linspace", "sample_b1_textclamp",
                 "sample_b1_duplicate", "sample_unett_b2"]
 
 

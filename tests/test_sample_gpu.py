@@ -22,7 +22,9 @@ TOL_16_BASE = {"bf16": 5e-2, "f16": 7e-3}
 TOL_BF16 = TOL_16["bf16"]
 
 CASES = ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_b1_editmask", "sample_b1_norefaudio",
-         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp", "sample_b1_duplicate", "sample_unett_b2"]
+         "sample_b2_v1arch", "sample_b1_nocfg_linspace", "sample_b1_textclamp", "sample_b1_duplicate", "sample_unett_b2",
+         # qk_norm="rms_norm" + long_skip_connection + text_embedding_average_upsampling (dit.py:160-166), all heads / head 0 rotary
+         "sample_b2_options", "sample_b1_options_pe1"]
 
 
 def build_cfm(meta, sd, precision):
@@ -94,7 +96,7 @@ def test_attn_mask_batch_unpacked_matches_reference_in_full(monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-@pytest.mark.parametrize("name", ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_unett_b2"])
+@pytest.mark.parametrize("name", ["sample_b1_nfe16", "sample_b3_masked", "sample_b3_attnmask", "sample_unett_b2", "sample_b2_options"])
 def test_sample_16bit_error_is_bounded_and_reported(name, prec):
     meta, a = load_golden(name)
     sd = synthetic_weights(meta)
