@@ -140,22 +140,37 @@ extern "C" int f5_reserve(f5_engine* e, int32_t B, int32_t N, int32_t S) {
 // actually present (C3 with attn_mask_enabled: 2 chunks of 16 utterances ~ 22,600 valid rows each).
 int chunk_utts(f5_engine* e, int B, int N, bool use_cfg, const int32_t* lens_host) {
     if (split_cfg_enabled(e)) return B;   // the opt-in two-stream mode steps the whole batch per half
-    // Budget 32,768 rows, equal chunks.  C3 (65,536 rows) on one box, end of round 2: 4 x 16,384 rows 1,460 ms, 3 x 21,845 1,515 (every
-    // GEMM pays a mostly empty last round of tiles), 2 x 32,768 **1,435**, 1 x 65,536 1,447; with packed rows (45,200 valid) 3 chunks
-    // 1,189, 2 chunks **1,113**.  (A model that counted rounds of 256x256 tiles per chunk preferred 3 packed chunks: removed.  Earlier
-    // in the round, before the residual GEMMs moved to two rounds of 256x128 tiles, 16,384 rows was the optimum: 1.48 vs 1.55 s.)
-    const long budget = getenv("F5_CHUNK_ROWS") ? atol(getenv("F5_CHUNK_ROWS")) : 32768;
+    // Equal chunks; how many is chosen by counting ROUNDS of GEMM tiles: a backbone call on R rows runs its N = 1024 GEMMs (out-proj, FF2) in
+    // ceil(R / 16,384) rounds of 256 tiles of 256 x 256, so k chunks cost k * ceil(R_chunk / 16,384) rounds; among the cheapest counts
+    // the one whose chunks are closest to 32,768 rows wins (the activations of such a chunk stay inside the Infinity Cache).  Measured:
+    // C3 padded (65,536 rows; 1 / 2 / 4 chunks all 4 rounds): 4 x 16,384 1,338 ms, **2 x 32,768 1,271**, 1 x 65,536 1,289; C3 with packed rows
+    // (45,200 valid rows): 2 x 22,600 (2 x 2 rounds) 1,103 ms, **1 x 45,200 (3 rounds) 1,018** -- round 2's fixed 32,768-row budget
+    // chose the former.  F5_CHUNK_ROWS forces a fixed budget instead (tests use tiny chunks).
     long rows_per_utt = (long)(use_cfg ? 2 : 1) * (N + (e->cfg.backbone == F5_BACKBONE_UNETT ? 1 : 0));
     if (lens_host && pack_rows_enabled(e)) {
         long total = 0;
         for (int i = 0; i < B; ++i) total += (lens_host[i] + 3) / 4 * 4;
         rows_per_utt = std::max(1L, (long)(use_cfg ? 2 : 1) * total / B);
     }
-    long bc = budget / rows_per_utt;
-    if (bc < 1) bc = 1;
-    if (bc >= B) return B;
-    const long nchunks = (B + bc - 1) / bc;
-    return (int)((B + nchunks - 1) / nchunks);   // equal-sized chunks (8 utterances, budget 7 -> 4 + 4, not 7 + 1)
+    if (getenv("F5_CHUNK_ROWS")) {
+        const long budget = atol(getenv("F5_CHUNK_ROWS"));
+        long bc = budget / rows_per_utt;
+        if (bc < 1) bc = 1;
+        if (bc >= B) return B;
+        const long nchunks = (B + bc - 1) / bc;
+        return (int)((B + nchunks - 1) / nchunks);   // equal-sized chunks (8 utterances, budget 7 -> 4 + 4, not 7 + 1)
+    }
+    const long total_rows = rows_per_utt * B;
+    const long kmin = std::max(1L, (total_rows + 65535) / 65536), kmax = std::min((long)B, std::max(kmin, total_rows / 12288));
+    long best_k = kmin, best_cost = -1, best_dist = 0;
+    for (long k = kmin; k <= kmax; ++k) {
+        const long per = (B + k - 1) / k, r = per * rows_per_utt;      // utterances / rows of a (full) chunk
+        const long kk = (B + per - 1) / per;                           // chunks that size actually gives
+        const long cost = kk * ((r + 16383) / 16384);
+        const long dist = std::labs(r - 32768);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && dist < best_dist)) { best_k = kk; best_cost = cost; best_dist = dist; }
+    }
+    return (int)((B + best_k - 1) / best_k);
 }
 static int check_ready(f5_engine* e, int B, int N) {
     if (!e) return fail(F5_EINVAL, "null engine");

@@ -193,10 +193,7 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
             CHK(copy_vec(e, s, p + ".1.g", {D}, &b.norm1_g));
             CHK(copy_vec(e, s, p + ".3.g", {D}, &b.norm2_g));
             if (i >= c.depth / 2 && e->ws.get(p + ".0.weight"))
-            {
                 CHK(pack_linear_bb<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
-                if (e->io_split) CHK((pack_linear<float, true>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip_f)));
-            }
         }
     }
     if (dit) {
@@ -295,7 +292,7 @@ template <typename T> static size_t carve_into(const f5_engine* e, Arena& a, Wor
     w.pred_all = nullptr;
     if (c.options & F5_OPT_LONG_SKIP) w.cat2 = a.take<T>(rows * 2 * D * (e->io_split ? sizeof(float) / sizeof(T) : 1));
     if (c.backbone == F5_BACKBONE_UNETT) {
-        w.cat2 = a.take<T>(rows * 2 * D * (e->io_split ? sizeof(float) / sizeof(T) : 1));   // (F5_PREC_F16P: f32 rows)
+        w.cat2 = a.take<T>(rows * 2 * D);
         w.skips = a.take<float>(rows * D * (c.depth / 2));
         w.pred_all = a.take<float>(rows * mel);
     }
@@ -634,17 +631,6 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         } else {
             const float* skip = w.skips + (size_t)(c.depth - 1 - l) * rows * D;   // LIFO (skips.pop())
             pr.begin(PC_MISC, s);
-            if (e->io_split) {   // F5_PREC_F16P: [x | skip] is the un-normalised f32 stream: split-f16 products on f32 rows
-                float* cat_f = reinterpret_cast<float*>(w.cat2);
-                hipLaunchKernelGGL((cat2_kernel<float>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, cat_f,
-                                   (long)rows, D);
-                KCHK();
-                pr.end(s);
-                pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
-                HIPCHK(launch_gemm<float>(s, cat_f, 2 * D, bw.skip_f.w, bw.skip_f.ldw, rows, D, 2 * D,
-                                          EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}, -1, nullptr, 0, GemmConv{}, 1));
-                pr.end(s);
-            } else {
             hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, w.cat2,
                                (long)rows, D);
             KCHK();
@@ -653,7 +639,6 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
                                   EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
             pr.end(s);
-            }
         }
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g, pl);

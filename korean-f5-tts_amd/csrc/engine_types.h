@@ -144,7 +144,6 @@ template <typename T> struct LinW {
 
 template <typename T> struct BlockW {
     LinW<T> qkv, out, ff1, ff2, skip;  // skip: UNetT concat projection (no bias)
-    LinW<float> skip_f;                // F5_PREC_F16P: the concat projection reads the RAW residual stream: split-planar f32 copy
     float* norm1_g = nullptr;          // UNetT RMSNorm gains
     float* norm2_g = nullptr;
     float *qn = nullptr, *kn = nullptr;   // F5_OPT_QK_RMSNORM: gains of the RMSNorm on q / k [64]
