@@ -161,3 +161,20 @@ def test_world1_no_collective():
     conds, texts, durs = make_job(5)
     mels, _ = D.dp_sample(FakeModel(), conds, texts, durs, batch_size=2, device="cpu")
     assert torch.allclose(mels, expected(conds, texts, durs))
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` outside torchrun starts its own N ranks -- and must fail loudly, before touching a GPU, when fewer
+    than N devices are visible (round 2 printed a one-GPU number with `n_gpus: 1` and rc 0).  No GPU here: --gpus 2 exits 2."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() >= 2:
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "GPU(s) are visible" in r.stderr and r.stdout.strip() == ""
+    # inside a launcher whose world size disagrees with --gpus: refuse as well
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
