@@ -121,11 +121,15 @@ extern "C" int f5x_block_gemm_time(int32_t M, int32_t cfg, int32_t iters, float*
     if (M <= 0 || M % 1024 || iters <= 0 || !us4) return fail(F5_EINVAL, "f5x_block_gemm_time: M must be a multiple of 1024");
     hipStream_t s = (hipStream_t)stream;
     typedef bf16_t T;
-    const int D = 1024, F = 2048, H = 16, N = 1024, ncopy = 8;
+    const int D = 1024, F = 2048, N = 1024, ncopy = 8;
+    // diagnostics: F5X_QKV_H = 24 makes the epilogue treat all 3,072 columns as q / k heads (no transposed V^T region: q / k buffers
+    // are allocated 1.5x), F5X_QKV_PE = heads that get rotary
+    const int H = getenv("F5X_QKV_H") ? atoi(getenv("F5X_QKV_H")) : 16;
+    const int PE = getenv("F5X_QKV_PE") ? atoi(getenv("F5X_QKV_PE")) : 1;
     Scratch<T> xn, ao, ffh, q, k, vt, wqkv, wout, wff1, wff2;
     Scratch<float> x, bias, gate, rope, rnd;
     HIPCHK(xn.alloc((size_t)M * D)); HIPCHK(ao.alloc((size_t)M * D)); HIPCHK(ffh.alloc((size_t)M * F));
-    HIPCHK(q.alloc((size_t)M * D)); HIPCHK(k.alloc((size_t)M * D)); HIPCHK(vt.alloc((size_t)M * D));
+    HIPCHK(q.alloc((size_t)M * D * 3 / 2)); HIPCHK(k.alloc((size_t)M * D * 3 / 2)); HIPCHK(vt.alloc((size_t)M * D));
     HIPCHK(wqkv.alloc((size_t)ncopy * 3 * D * D)); HIPCHK(wout.alloc((size_t)ncopy * D * D));
     HIPCHK(wff1.alloc((size_t)ncopy * F * D)); HIPCHK(wff2.alloc((size_t)ncopy * D * F));
     HIPCHK(x.alloc((size_t)M * D)); HIPCHK(bias.alloc(3 * D)); HIPCHK(gate.alloc((size_t)(M / N) * D)); HIPCHK(rope.alloc((size_t)2 * N * 32));
@@ -155,7 +159,7 @@ extern "C" int f5x_block_gemm_time(int32_t M, int32_t cfg, int32_t iters, float*
         const int c = (it + 2) % ncopy;
         HIPCHK(hipEventRecord(ev[0], s));
         HIPCHK(launch_gemm<T>(s, xn.p, D, wqkv.p + (size_t)c * 3 * D * D, D, M, 3 * D, D,
-                              EpiQKV<T>{q.p, k.p, vt.p, bias.p, rope.p, rope.p + N * 32, N, N, H, 1, 0.18f, nullptr}, cfg));
+                              EpiQKV<T>{q.p, k.p, vt.p, bias.p, rope.p, rope.p + N * 32, N, N, H, PE, 0.18f, nullptr}, cfg));
         HIPCHK(hipEventRecord(ev[1], s));
         HIPCHK(launch_gemm<T>(s, ao.p, D, wout.p + (size_t)c * D * D, D, M, D, D, EpiGateRes{x.p, x.p, D, bias.p, gate.p, D, N, nullptr}, cfg));
         HIPCHK(hipEventRecord(ev[2], s));
