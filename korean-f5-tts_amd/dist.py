@@ -20,7 +20,7 @@ def utterance_cost(n_frames: int) -> float:
 # One backbone call works on at most 32,768 rows (csrc/engine.hip::chunk_utts: the activations of a chunk stay inside the
 # Infinity Cache) = 16,384 frames with CFG: a batch larger than that is stepped chunk by chunk anyway, so a bigger batch
 # buys nothing and only pads more rows to its longest member.
-MAX_BATCH_FRAMES = 16384
+MAX_BATCH_FRAMES = int(__import__("os").environ.get("F5_MAX_BATCH_FRAMES", "16384"))   # (the override is for tools / A-B runs)
 
 
 # Row granules of the four block GEMMs on 256 CUs with 256 x 256 output tiles (csrc/gemm3.h): a launch runs whole ROUNDS of 256
