@@ -579,7 +579,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     Prof& pr = e->prof;
     auto gfl = [&](double r, double n, double k) { return 2.0 * r * n * k; };
     const double conv_fl = 2.0 * rows_in * D * (D / 16) * 31;
-    float* emb = w.skips;  // free until the layer loop pushes the first skip; conv input and output must not alias
+    float* emb = reinterpret_cast<float*>(w.cat2);  // [rows, 2D] of T >= [rows_in, D] f32; free until the first concat; conv input and output must not alias
     if (e->io_split) {   // F5_PREC_F16P: input projection + conv position embedding as split-f16 products on f32 operands (run_dit_forward)
         float* acat_f = reinterpret_cast<float*>(w.acat);
         pr.begin(PC_MISC, s);
@@ -616,19 +616,22 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     pr.end(s);
     }
     pr.begin(PC_MISC, s);
-    hipLaunchKernelGGL(unett_assemble_kernel, dim3(ew_blocks((long)rows * D / 4)), dim3(256), 0, s, emb, temb, temb_stride, w.x,
-                       Bp, N, D);
+    // The skip stack needs no copies: the stream entering block l < depth/2 is WRITTEN into skip slot l (by the assemble kernel / the
+    // FF2 epilogue of block l - 1), the block's first residual update reads it there and writes w.x, and nothing writes the slot again.
+    const int half = c.depth / 2;
+    auto slot = [&](int l) { return w.skips + (size_t)l * rows * D; };
+    hipLaunchKernelGGL(unett_assemble_kernel, dim3(ew_blocks((long)rows * D / 4)), dim3(256), 0, s, emb, temb, temb_stride,
+                       half > 0 ? slot(0) : w.x, Bp, N, D);
     KCHK();
     pr.end(s);
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;   // lens_dev holds len + 1 for UNetT
-    const int half = c.depth / 2;
     const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh written pre-split (as in run_dit_forward)
     for (int l = 0; l < c.depth; ++l) {
         BlockW<T>& bw = P.blocks[l];
-        if (l < half) {
-            HIPCHK(hipMemcpyAsync(w.skips + (size_t)l * rows * D, w.x, (size_t)rows * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-        } else {
+        const float* x_in = l < half ? slot(l) : w.x;            // the stream entering the block (= skips.append(x), unett.py:258-259)
+        float* x_out = l + 1 < half ? slot(l + 1) : w.x;         // where the block leaves it
+        if (l >= half) {
             const float* skip = w.skips + (size_t)(c.depth - 1 - l) * rows * D;   // LIFO (skips.pop())
             pr.begin(PC_MISC, s);
             hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, w.cat2,
@@ -641,7 +644,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             pr.end(s);
         }
         pr.begin(PC_LN, s);
-        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm1_g, pl);
+        hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, x_in, D, w.xn, D, rows, D, bw.norm1_g, pl);
         KCHK();
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
@@ -654,7 +657,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
         HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
-                              EpiGateRes{w.x, w.x, D, bw.out.b, nullptr, 0, Nt, lens_dev}, -1, nullptr, 0, pl));
+                              EpiGateRes{w.x, x_in, D, bw.out.b, nullptr, 0, Nt, lens_dev}, -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_LN, s);
         hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm2_g, pl);
@@ -664,7 +667,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH, pl}, -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, D, F));
-        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{w.x, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}, -1, nullptr, 0, pl));
+        HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{x_out, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}, -1, nullptr, 0, pl));
         pr.end(s);
     }
     if (e->io_split) {   // F5_PREC_F16P: final norm to pre-split f32 rows (in the skip stack's first slot: every skip has been popped) + split projection
