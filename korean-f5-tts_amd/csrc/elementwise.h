@@ -635,6 +635,18 @@ static __global__ void split_planar_kernel(float* __restrict__ w, long blocks) {
 static __global__ void round_f16_kernel(const float* __restrict__ in, float* __restrict__ out, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)(f16_t)in[i];
 }
+// The rotary table in the order the QKV epilogue's accumulator lanes read it (EpiQKV, gemm.h): out[pos][g][j] = {cos, cos, sin, sin} of
+// the pairs (j*8 + g*2, j*8 + g*2 + 1) from the [maxpos][32] tables (modules.py:398-424 / x_transformers RotaryEmbedding values).
+static __global__ __launch_bounds__(256) void rope_frag_kernel(const float* __restrict__ cs, const float* __restrict__ sn, float* __restrict__ out,
+                                                        long maxpos) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < maxpos * 16; i += (long)gridDim.x * blockDim.x) {   // one (pos, g, j)
+        const long pos = i >> 4;
+        const int g = (int)(i >> 2) & 3, j = (int)i & 3, pair = j * 8 + g * 2;
+        const float2 c = *reinterpret_cast<const float2*>(cs + pos * 32 + pair), s2 = *reinterpret_cast<const float2*>(sn + pos * 32 + pair);
+        *reinterpret_cast<float4*>(out + i * 4) = make_float4(c.x, c.y, s2.x, s2.y);
+    }
+}
+
 // Diagnostic (F5_X3_ABLATE, tools/x3_ablate.py): zeroes the lo halves (chunks 4..7 of every 128-byte block) of a split-planar
 // operand in place, which turns the three-product f16x3 contraction into the plain f16 one (a_hi w_hi) for that operand.
 static __global__ void zero_lo_planar_kernel(float* __restrict__ w, long blocks) {

@@ -112,6 +112,9 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
     e->cfg.max_pos = (int)maxpos;
     CHK(copy_vec(e, s, "aux.rope_cos", {maxpos, 32}, &P.rope_cos));
     CHK(copy_vec(e, s, "aux.rope_sin", {maxpos, 32}, &P.rope_sin));
+    CHK(dev_alloc(e, &P.rope_frag, (size_t)maxpos * 64));
+    hipLaunchKernelGGL(rope_frag_kernel, dim3(ew_blocks(maxpos * 16)), dim3(256), 0, s, P.rope_cos, P.rope_sin, P.rope_frag, (long)maxpos);
+    KCHK();
     CHK(copy_vec(e, s, "aux.time_freqs", {128}, &P.time_freqs));
     // time MLP
     CHK(pack_linear<float>(e, s, "time_embed.time_mlp.0.weight", "time_embed.time_mlp.0.bias", D, 256, &P.time0));
@@ -481,7 +484,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, N, w.Npad, H, qk_norm ? 0 : pe_heads,
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_frag, N, w.Npad, H, qk_norm ? 0 : pe_heads,
                                         qk_norm ? 1.0f : attention_q_scale<T>(), pk.rowmap},
                               -1, ml, mh, pl));
         pr.end(s);
@@ -649,7 +652,7 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         pr.end(s);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
-                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_cos, P.rope_sin, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()},
+                              EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_frag, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()},
                               -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);

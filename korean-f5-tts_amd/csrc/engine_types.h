@@ -173,6 +173,7 @@ template <typename T> struct Packed {
     float* norm_out_g = nullptr;  // UNetT
     // aux tables
     float *rope_cos = nullptr, *rope_sin = nullptr, *time_freqs = nullptr, *text_pos = nullptr;
+    float* rope_frag = nullptr;   // rope_cos / rope_sin in the QKV epilogue's fragment order (rope_frag_kernel)
     int text_pos_rows = 0;
 };
 

@@ -238,10 +238,14 @@ struct EpiGateRes {
 // of (m / Nseq, m % Nseq); every utterance then starts at a multiple of 4 rows, and positions >= Nseq (alignment rows
 // of the longest utterance) are dropped.
 template <typename TO> struct EpiQKV {
-    TO* q; TO* k; TO* vt; const float* bias; const float* rope_cos; const float* rope_sin;  // [maxpos][32]
+    // rope: the rotary table in FRAGMENT order (rope_frag_kernel, elementwise.h): [maxpos][g = 0..3][j = 0..3]{cos, cos, sin, sin} of the
+    // pairs (j*8 + g*2, +1) -- the 4 columns j*16 + g*4 .. +3 of a head that one accumulator lane owns need ONE 16-byte load, and a lane's
+    // four sub-tiles j are 64 contiguous bytes (two tables of [maxpos][32] cost four 8-byte loads per sub-tile pair: all-heads rotary,
+    // pe_attn_head = None, was +38 us per 32,768-row QKV launch)
+    TO* q; TO* k; TO* vt; const float* bias; const float* rope;
     int Nseq, Npad, H, pe_heads; float q_scale;
     const int2* rowmap = nullptr;
-    struct RowCtx { size_t base; const float* cs; const float* sn; };      // base = (b*H*Nseq + pos) * 64; cs == null: drop
+    struct RowCtx { size_t base; const float* cs; };      // base = (b*H*Nseq + pos) * 64; cs = the position's 64 table floats; null: drop
     struct ColCtx { float4 b; TO* dst; size_t hoff; int d; bool rot; float scale; };
     struct TRowCtx { size_t base; int pos; int b; bool fast; int m; int M; };
     struct TColCtx { float b; size_t hoff; };
@@ -250,8 +254,8 @@ template <typename TO> struct EpiQKV {
     __device__ __forceinline__ RowCtx row(int m) const {
         int b = m / Nseq, pos = m - b * Nseq;
         if (rowmap) { const int2 bp = rowmap[m]; b = bp.x; pos = bp.y; }
-        if (pos >= Nseq) return {0, nullptr, nullptr};
-        return {((size_t)b * H * Nseq + pos) * 64, rope_cos + pos * 32, rope_sin + pos * 32};
+        if (pos >= Nseq) return {0, nullptr};
+        return {((size_t)b * H * Nseq + pos) * 64, rope + pos * 64};
     }
     __device__ __forceinline__ ColCtx col(int n) const {
         const int inner = H * 64;
@@ -262,7 +266,8 @@ template <typename TO> struct EpiQKV {
     struct Pre { float2 cs, sn; };
     __device__ __forceinline__ Pre preload(const RowCtx& r, const ColCtx& c) const {
         if (!c.rot || !r.cs) return {make_float2(1, 1), make_float2(0, 0)};
-        return {*reinterpret_cast<const float2*>(r.cs + (c.d >> 1)), *reinterpret_cast<const float2*>(r.sn + (c.d >> 1))};
+        const float4 t = *reinterpret_cast<const float4*>(r.cs + ((c.d >> 2) & 3) * 16 + (c.d >> 4) * 4);   // d = j*16 + g*4
+        return {make_float2(t.x, t.y), make_float2(t.z, t.w)};
     }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, f32x4 v, const Pre& p) const {
         float a0 = v[0] + c.b.x, a1 = v[1] + c.b.y, a2 = v[2] + c.b.z, a3 = v[3] + c.b.w;
@@ -328,17 +333,15 @@ template <typename TO> struct EpiQKV {
             if (rot) {
 #pragma unroll
                 for (int ih = 0; ih < 4; ++ih) {
-                    float2 cs[2][NJ], sn[2][NJ];
+                    float4 t[2][NJ];
 #pragma unroll
                     for (int i4 = 0; i4 < 2; ++i4) {
                         const int m = mw + (ih * 2 + i4) * 16 + l15;
                         int pos = m - (m / Nseq) * Nseq;
                         if (rowmap) pos = min(rowmap[m].y, Nseq - 1);   // (alignment rows of a packed utterance: any valid table row, dropped below)
+                        const float4* tp = reinterpret_cast<const float4*>(rope + pos * 64 + g * 16);
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) {
-                            cs[i4][j] = *reinterpret_cast<const float2*>(rope_cos + pos * 32 + ((j * 16 + g * 4) >> 1));
-                            sn[i4][j] = *reinterpret_cast<const float2*>(rope_sin + pos * 32 + ((j * 16 + g * 4) >> 1));
-                        }
+                        for (int j = 0; j < NJ; ++j) t[i4][j] = tp[j];
                     }
 #pragma unroll
                     for (int i4 = 0; i4 < 2; ++i4)
@@ -346,7 +349,7 @@ template <typename TO> struct EpiQKV {
                         for (int j = 0; j < NJ; ++j) {
                             const f32x4 v = acc[ih * 2 + i4][j];
                             const float a0 = v[0] + bj[j].x, a1 = v[1] + bj[j].y, a2 = v[2] + bj[j].z, a3 = v[3] + bj[j].w;
-                            const float2 c = cs[i4][j], sv = sn[i4][j];
+                            const float2 c = make_float2(t[i4][j].x, t[i4][j].y), sv = make_float2(t[i4][j].z, t[i4][j].w);
                             put(ih * 2 + i4, j, a0 * c.x - a1 * sv.x, a1 * c.x + a0 * sv.x, a2 * c.y - a3 * sv.y, a3 * c.y + a2 * sv.y);
                         }
                 }

@@ -159,7 +159,7 @@ extern "C" int f5x_block_gemm_time(int32_t M, int32_t cfg, int32_t iters, float*
         const int c = (it + 2) % ncopy;
         HIPCHK(hipEventRecord(ev[0], s));
         HIPCHK(launch_gemm<T>(s, xn.p, D, wqkv.p + (size_t)c * 3 * D * D, D, M, 3 * D, D,
-                              EpiQKV<T>{q.p, k.p, vt.p, bias.p, rope.p, rope.p + N * 32, N, N, H, PE, 0.18f, nullptr}, cfg));
+                              EpiQKV<T>{q.p, k.p, vt.p, bias.p, rope.p, N, N, H, PE, 0.18f, nullptr}, cfg));
         HIPCHK(hipEventRecord(ev[1], s));
         HIPCHK(launch_gemm<T>(s, ao.p, D, wout.p + (size_t)c * D * D, D, M, D, D, EpiGateRes{x.p, x.p, D, bias.p, gate.p, D, N, nullptr}, cfg));
         HIPCHK(hipEventRecord(ev[2], s));
@@ -218,7 +218,7 @@ extern "C" int f5x_pair_time(int32_t M, int32_t N, int32_t K, int32_t cfg, int32
     HIPCHK(hipMemsetAsync(tab.p, 0, ((size_t)2 * 4096 * 32 + N) * 4, s));
     static int variant = getenv("F5X_QKV_VARIANT") ? atoi(getenv("F5X_QKV_VARIANT")) : 0;
     auto gq = [&](int i) -> hipError_t {
-        EpiQKV<T> e{q3.p, q3.p + (size_t)M * 1024, q3.p + (size_t)2 * M * 1024, tab.p + 2 * 4096 * 32, tab.p, tab.p + 4096 * 32,
+        EpiQKV<T> e{q3.p, q3.p + (size_t)M * 1024, q3.p + (size_t)2 * M * 1024, tab.p + 2 * 4096 * 32, tab.p,
                     1024, 1024, 16, 1, 0.125f};
         if (variant == 1) { e.H = 24; e.k = q3.p + (size_t)M * 1536; }  // no transposed third: q | k of 24 heads each
         if (variant == 2) e.pe_heads = 0;                                 // no rotary
