@@ -94,6 +94,9 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     // A many-row problem whose row count is a few rows past a multiple of 256 (UNetT: 16 x 1025 = 16,400 rows) would pay
     // a whole extra round of 256-row tiles for the last 16 rows: the 256-row multiple goes to the ping-pong kernel and the
     // remainder to one row of 64x64 tiles (same K order per element: bit-identical to a single launch).
+    // (Tried for the remainder launch and dropped: running it BESIDE the main launch on a second stream -- fork / join events, in the
+    // captured graph a two-node parallel branch per GEMM -- C5 350.5 -> 356.0 ms: the cross-stream dependencies of 1,920 branches cost
+    // more than the ~20 ms of remainder launches they hide.  Deeper LDS-DMA rings for its 64x64 tiles (6, 8 stages): 6.3 -> 6.5-6.8 us.)
     // (Round 2 sent the residual epilogue -- EpiGateRes reads and writes the f32 stream, 268 MB per launch at 32,768 rows -- to two
     // rounds of 256x128 tiles because the ping-pong kernel's fragment-order epilogue overlapped with nothing.  With the staged
     // row-major epilogue (gemm.h) the ping-pong tile wins there too: tools/block_gemm_time.py, 32,768 rows, out-proj / FF2.)
