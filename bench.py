@@ -32,10 +32,12 @@ Beside it, every line carries
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -174,6 +176,64 @@ def cpu_baseline(P, args, sd, vsd, cond, text):
                       f"decode of {gen} frames ({statistics.median(voc_s):.2f} s)"}
 
 
+class ClockWatch:
+    """Shader clock and socket power of THIS rank's GPU while a region runs, read from the amdgpu hwmon files (sysfs, read-only, no
+    child process): `with ClockWatch(dev) as cw: ...; cw.summary()`.  Informational -- the MI355X lowers its clock under sustained
+    matrix load, so a roofline fraction priced at the nominal 2.4 GHz understates what the kernels do per cycle.  Returns None
+    where the files are missing or the card cannot be matched by PCI address."""
+
+    def __init__(self, dev_index, period=0.02):
+        self.period, self.samples, self.dir, self.cap = period, [], None, None
+        self._stop = threading.Event()
+        self._thr = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if os.path.realpath(c).endswith(bdf):
+                    hw = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+                    if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                        self.dir = hw[0]
+            if self.dir and os.path.exists(os.path.join(self.dir, "power1_cap")):
+                self.cap = int(open(os.path.join(self.dir, "power1_cap")).read()) / 1e6
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            return int(open(os.path.join(self.dir, name)).read())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            f, pw = self._read("freq1_input"), self._read("power1_input")
+            if f is not None:
+                self.samples.append((f / 1e6, pw / 1e6 if pw is not None else None))
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.dir:
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr:
+            self._thr.join()
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        fs = [a for a, _ in self.samples]
+        ps = [b for _, b in self.samples if b is not None]
+        return {"sclk_mhz_avg": round(sum(fs) / len(fs), 1), "sclk_mhz_min": round(min(fs), 1), "sclk_mhz_nominal": 2400,
+                "power_w_avg": round(sum(ps) / len(ps), 1) if ps else None, "power_cap_w": self.cap, "samples": len(fs),
+                "source": "amdgpu hwmon freq1_input / power1_input, sampled every %d ms during the timed region" % int(self.period * 1e3)}
+
+
 def free_port() -> int:
     import socket
     with socket.socket() as so:
@@ -300,11 +360,12 @@ def main():
     for _ in range(args.warmup):
         out, wav = step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, wav = step()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    with ClockWatch(dev.index) as cw:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, wav = step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(out).all() and torch.isfinite(wav).all()
 
     audio_per_step = gen_frames_total * 256 / 24000
@@ -326,6 +387,7 @@ def main():
                    "global_batch": B * world, "frames": N, "generated_audio_sec_per_step": audio_per_step * world,
                    "parallelism": "dp%d" % world, "weights": "synthetic random-init seed 0"},
     }
+    result["clocks"] = cw.summary()   # rank 0's GPU during the timed region (None where sysfs does not offer it)
     if world > 1:
         result["rccl_ranks"] = dist.get_world_size()
         result["collective_backend"] = dist.get_backend()
@@ -480,14 +542,15 @@ def main():
             for _ in range(3):   # arena growth (eager), graph capture, first replay
                 o3 = step3()
             torch.cuda.synchronize()
-            a = time.perf_counter()
-            for _ in range(2):
-                o3 = step3()
-            torch.cuda.synchronize()
-            ms3 = (time.perf_counter() - a) / 2 * 1e3
+            with ClockWatch(dev.index) as cw3:
+                a = time.perf_counter()
+                for _ in range(2):
+                    o3 = step3()
+                torch.cuda.synchronize()
+                ms3 = (time.perf_counter() - a) / 2 * 1e3
             assert torch.isfinite(o3).all()
             rec3["attn_mask_enabled=%s" % mask] = {
-                "ms_per_step": ms3, "value": audio3 / (ms3 * 1e-3), "rtf_wall_over_audio": ms3 * 1e-3 / audio3,
+                "ms_per_step": ms3, "value": audio3 / (ms3 * 1e-3), "rtf_wall_over_audio": ms3 * 1e-3 / audio3, "clocks": cw3.summary(),
                 "whole_path_tflops_valid_tokens": fl3 / (ms3 * 1e-3) / 1e12,
                 "rows": "valid rows only (RowPack)" if mask else "all padded rows (bug-compatible with the reference's unmasked softmax)"}
             del m3, o3
@@ -509,10 +572,11 @@ def main():
         for _ in range(args.c4_warm_passes):
             job()
         barrier()
-        t0 = time.perf_counter()
-        mels, _lens = job()
-        barrier()
-        el4 = max_over_ranks(time.perf_counter() - t0)
+        with ClockWatch(dev.index) as cw4:
+            t0 = time.perf_counter()
+            mels, _lens = job()
+            barrier()
+            el4 = max_over_ranks(time.perf_counter() - t0)
         assert torch.isfinite(mels).all() and mels.shape == (args.c4_utts, max(durs4), 100)
         shards4 = D.partition(durs4, world, 32)
         audio4 = gen4 * 256 / 24000
@@ -522,7 +586,7 @@ def main():
                         "sway -1, sharded over %d rank(s) by dist.dp_sample (contiguous slices of the length-sorted list with equal "
                         "padded cost, frame-budget batches of <= 32 utterances / %d frames), ONE all_gather of the generated mel; "
                         "no vocoder" % (args.c4_utts, args.precision, world, D.MAX_BATCH_FRAMES),
-            "value": audio4 / el4, "unit": "audio_sec/wall_sec", "scaling": "strong", "n_gpus": world, "wall_sec": el4,
+            "value": audio4 / el4, "unit": "audio_sec/wall_sec", "scaling": "strong", "n_gpus": world, "wall_sec": el4, "clocks": cw4.summary(),
             "generated_audio_sec": audio4, "utterances_per_rank": [len(s) for s in shards4],
             "batches_per_rank": [len(D.batches_of(s, durs4, 32)) for s in shards4],
             "padded_over_ideal_cost_per_rank": [round(D.padded_cost(s, durs4, 32) / (valid4 / world), 4) for s in shards4],

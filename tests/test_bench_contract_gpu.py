@@ -31,5 +31,6 @@ def test_bench_line_contract():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.02 < rf["frac"] < 1.0
     assert rf["traffic"] is None or rf["traffic"] > 0
+    assert "clocks" in d and (d["clocks"] is None or 500 < d["clocks"]["sclk_mhz_avg"] <= 2600)
     c4 = d["c4"]
     assert c4["scaling"] == "strong" and c4["n_gpus"] == 1 and len(c4["shard8_wall_sec"]) == 8 and c4["predicted_scaling_8"] > 1.0
