@@ -467,7 +467,7 @@ def main():
             if args.workload == "c2" and args.precision in ("bf16", "f16", "f16p") and os.path.exists(tfile):
                 # HBM-side bytes per launch of this kernel class: NOT measured in this run (PMC counters need rocprofv3
                 # around the process); collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this
-                # same command (tools/pmc_bench.sh) and committed under profiles/; refreshed whenever the GEMM changes
+                # workload (tools/pmc_pass.sh over tools/pmc_one.py) and committed under profiles/; refreshed whenever the GEMM changes
                 tj = json.load(open(tfile))
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_source = "%s (%s)" % (TRAFFIC_FILE, tj.get("collected", "rocprofv3 --pmc passes of this command"))
