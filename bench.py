@@ -477,6 +477,9 @@ def main():
                 "traffic_source": traffic_source,
                 "launches": gm["launches"], "avg_launch_us": gm["ms"] * 1e3 / max(gm["launches"], 1),
                 "flops_per_launch_avg": gm["flops"] / max(gm["launches"], 1),
+                "note": "durations are per-launch HIP event pairs on an eager pass over the same workload: each includes its launch "
+                        "boundary (the classes sum to more than ms_per_step), so `achieved` is a LOWER bound; rocprofv3's kernel-only "
+                        "averages of the same command are in profiles/ (r03_k_rocprof_kernel_stats_c2_summary.txt)",
             }
             result["kernel_classes"] = {
                 k: {"ms": round(v["ms"], 3), "launches": v["launches"],
