@@ -178,3 +178,15 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_clock_watch_is_inert_without_gpu_sysfs():
+    """bench.py's ClockWatch must never fail a run: with no GPU (here) or no hwmon files it samples nothing and reports None."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    cw = bench.ClockWatch(0)
+    with cw:
+        pass
+    assert cw.summary() is None
