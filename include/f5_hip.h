@@ -37,7 +37,9 @@ extern "C" {
                             bf16, 3 more mantissa bits), f32 accumulate, f32 residual stream / ODE state / norms */
 #define F5_PREC_F16X3 3  /* f32 data flow (activations, attention, norms as F5_PREC_F32); each GEMM operand is split into two fp16
                             halves (hi + lo, 22 bits) and the product takes three fp16 MFMAs: f32-level results; the backbone GEMMs run
-                            at ~2.5-3x the f32 MFMA rate, a C2 utterance in 0.46x the f32 time.  |activation| < 65504 as for F5_PREC_F16 */
+                            at ~2.5-3x the f32 MFMA rate, a C2 utterance in 0.41x the f32 time.  The two attention products
+                            use the hi halves only (plain fp16 products: measured harmless; F5_X3_ATTN_SPLIT=1 for three).
+                            |activation| < 65504 as for F5_PREC_F16 */
 
 #define F5_PREC_F16P 4   /* F5_PREC_F16 in the transformer blocks (fp16 MFMA operands, f32 accumulate / residual / norms) with the
                             model's input and output layers -- input projection, conv position embedding, final norm + output

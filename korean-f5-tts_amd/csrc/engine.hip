@@ -66,6 +66,7 @@ extern "C" int f5_create(const f5_config* c, f5_engine** out) {
     e->split16 = c->precision == F5_PREC_F16X3;
     e->io_split = c->precision == F5_PREC_F16P;
     if (e->split16 && getenv("F5_X3_ABLATE")) e->x3_ablate = atoi(getenv("F5_X3_ABLATE"));
+    if (getenv("F5_X3_ATTN_SPLIT") && getenv("F5_X3_ATTN_SPLIT")[0] == '1') e->x3_attn_hi = (e->x3_ablate >> 1) & 3;
     *out = e;
     return F5_OK;
 }

@@ -195,8 +195,16 @@ template <typename T> static int finalize_t(f5_engine* e, Packed<T>& P, hipStrea
         } else {
             CHK(copy_vec(e, s, p + ".1.g", {D}, &b.norm1_g));
             CHK(copy_vec(e, s, p + ".3.g", {D}, &b.norm2_g));
-            if (i >= c.depth / 2 && e->ws.get(p + ".0.weight"))
+            if (i >= c.depth / 2 && e->ws.get(p + ".0.weight")) {
                 CHK(pack_linear_bb<T>(e, s, p + ".0.weight", "", D, 2 * D, &b.skip));
+                if constexpr (std::is_same_v<T, float>) {
+                    if (e->x3_ablate & 512) {   // diagnostic: the skip projection with plain f16 weights
+                        const long blocks = (long)b.skip.N * b.skip.ldw / 32;
+                        hipLaunchKernelGGL(zero_lo_planar_kernel, dim3(ew_blocks(blocks * 4)), dim3(256), 0, s, b.skip.w, blocks);
+                        HIPCHK(hipGetLastError());
+                    }
+                }
+            }
         }
     }
     if (dit) {
@@ -498,7 +506,7 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         }
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl,
-                                    (e->x3_ablate >> 1) & 3));
+                                    e->x3_attn_hi));
         pr.end(s);
         ablate_a(8, w.ao, inner);
         pr.begin(PC_GEMM, s, gflops(D, inner));
@@ -630,6 +638,14 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
     const int pe_heads = c.pe_attn_head < 0 ? H : c.pe_attn_head;
     const int* attn_lens = (c.attn_mask_enabled && lens_dev) ? lens_dev : nullptr;   // lens_dev holds len + 1 for UNetT
     const int pl = e->split16 ? 1 : 0;   // F5_PREC_F16X3: xn / ao / ffh written pre-split (as in run_dit_forward)
+    auto ablate_a = [&](int bit, T* a, int k) {   // diagnostic F5_X3_ABLATE (run_dit_forward): the class's A operand as plain f16
+        if constexpr (std::is_same_v<T, float>) {
+            if (e->x3_ablate & bit) {
+                const long blocks = (long)rows * k / 32;
+                hipLaunchKernelGGL(zero_lo_planar_kernel, dim3(ew_blocks(blocks * 4)), dim3(256), 0, s, a, blocks);
+            }
+        }
+    };
     for (int l = 0; l < c.depth; ++l) {
         BlockW<T>& bw = P.blocks[l];
         const float* x_in = l < half ? slot(l) : w.x;            // the stream entering the block (= skips.append(x), unett.py:258-259)
@@ -641,6 +657,10 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
                                (long)rows, D);
             KCHK();
             pr.end(s);
+            if constexpr (std::is_same_v<T, float>) {
+                if (e->x3_ablate & 512)   // diagnostic: ... and its (unsplit f32) A operand as f16 sees it
+                    hipLaunchKernelGGL(round_f16_kernel, dim3(ew_blocks((long)rows * 2 * D)), dim3(256), 0, s, w.cat2, w.cat2, (long)rows * 2 * D);
+            }
             pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
             HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
                                   EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
@@ -650,14 +670,17 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, x_in, D, w.xn, D, rows, D, bw.norm1_g, pl);
         KCHK();
         pr.end(s);
+        ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_frag, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()},
                               -1, nullptr, 0, pl));
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
-        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16, pl));
+        HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16, pl,
+                                    e->x3_attn_hi));
         pr.end(s);
+        ablate_a(8, w.ao, inner);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
         HIPCHK(egemm<T>(e, s, w.ao, inner, bw.out.w, bw.out.ldw, rows, D, inner,
                               EpiGateRes{w.x, x_in, D, bw.out.b, nullptr, 0, Nt, lens_dev}, -1, nullptr, 0, pl));
@@ -666,9 +689,11 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         hipLaunchKernelGGL((xrmsnorm_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, s, w.x, D, w.xn, D, rows, D, bw.norm2_g, pl);
         KCHK();
         pr.end(s);
+        ablate_a(16, w.xn, D);
         pr.begin(PC_GEMM, s, gfl(rows, F, D));
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.ff1.w, bw.ff1.ldw, rows, F, D, EpiStore<T>{w.ffh, F, bw.ff1.b, F5_ACT_GELU_TANH, pl}, -1, nullptr, 0, pl));
         pr.end(s);
+        ablate_a(32, w.ffh, F);
         pr.begin(PC_GEMM, s, gfl(rows, D, F));
         HIPCHK(egemm<T>(e, s, w.ffh, F, bw.ff2.w, bw.ff2.ldw, rows, D, F, EpiGateRes{x_out, w.x, D, bw.ff2.b, nullptr, 0, Nt, nullptr}, -1, nullptr, 0, pl));
         pr.end(s);

@@ -186,6 +186,10 @@ struct f5_engine {
     // (hi x hi only) instead of the three split products: 1 QKV, 2 attention K Q^T, 4 attention V^T P^T, 8 out-proj, 16 FF1, 32 FF2,
     // 64 input projection, 128 conv position embedding, 256 output projection
     int x3_ablate = 0;
+    // F5_PREC_F16X3 attention: both products (K Q^T, V^T P^T) as PLAIN f16 products on the split operands' hi halves -- measured harmless
+    // (tools/x3_ablate.py: DiT C2 1.10e-5 -> 1.01e-5, E2-TTS UNetT 1.7e-5 -> 5.2e-5; every GEMM class costs ~1e-3 there) and 7-9 % of
+    // the f16x3 step.  F5_X3_ATTN_SPLIT=1 restores the three split products (and lets F5_X3_ABLATE bits 2 / 4 select).
+    int x3_attn_hi = 3;
     WeightStore ws;
     std::vector<void*> owned;  // packed buffers
     Packed<float> pf;

@@ -7,6 +7,8 @@ frames, NFE=16, cfg 2, sway -1): trajectory / generated-mel L-inf against the ex
 at 6.6e-6 at this size, tests/test_configs_gpu.py).  north_star's bar is 1e-3; with a 2x margin a mix must stay below 5e-4.
 
     python tools/x3_ablate.py            (on the GPU box; ~1 minute)
+    python tools/x3_ablate.py unett      the E2-TTS UNetT Base instead (B=2; no AdaLN gates: its blocks' own products dominate; bit 512 =
+                                         the skip projections)
 """
 import json
 import os
@@ -20,19 +22,27 @@ import torch  # noqa: E402
 torch.set_num_threads(1)
 import f5_tts_amd as P  # noqa: E402
 
+UNETT = len(sys.argv) > 1 and sys.argv[1] == "unett"
 CLASSES = {"qkv": 1, "attn_qk": 2, "attn_pv": 4, "out": 8, "ff1": 16, "ff2": 32, "in_proj": 64, "conv_pos": 128, "proj_out": 256}
+if UNETT:
+    CLASSES["skip_proj"] = 512
 dev = torch.device("cuda:0")
 nv = P.config.VOCAB_SIZE + 1
 N, ref, nfe = 1024, 256, 16
+BB = 2 if UNETT else 1
 g = torch.Generator().manual_seed(1)
-cond = torch.randn(1, ref, 100, generator=g).to(dev)
-text = torch.randint(1, nv - 2, (1, round(0.15 * N)), generator=g)
+cond = torch.randn(BB, ref, 100, generator=g).to(dev)
+text = torch.randint(1, nv - 2, (BB, round(0.15 * N)), generator=g)
 kw = dict(steps=nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
 
 
 def build(prec, mask=0):
     os.environ["F5_X3_ABLATE"] = str(mask)
-    tr = P.DiT(**P.config.F5TTS_BASE, text_num_embeds=nv, mel_dim=100, precision=prec).init_synthetic(seed=0)
+    os.environ["F5_X3_ATTN_SPLIT"] = "1"      # (the product default is plain-f16 attention products; here the mask decides)
+    if UNETT:
+        tr = P.UNetT(**P.config.E2TTS_BASE, text_num_embeds=nv, mel_dim=100, precision=prec).init_synthetic(seed=0)
+    else:
+        tr = P.DiT(**P.config.F5TTS_BASE, text_num_embeds=nv, mel_dim=100, precision=prec).init_synthetic(seed=0)
     m = P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(dev)
     tr.engine()          # f5_create reads the environment
     return m
@@ -61,7 +71,9 @@ for prec in ("f16", "bf16"):
                  "mel_linf": float((o[:, ref:] - ref_out[:, ref:]).abs().max()), "ms_sample": ms})
 masks = [("f16x3 (all classes split)", 0)]
 masks += [("f16 products in: " + k, v) for k, v in CLASSES.items()]
-masks += [("f16 products in: attn_qk + attn_pv", 6), ("f16 products in: all four block GEMMs", 57), ("f16 products in: the 22 blocks (GEMMs + attention)", 63),
+if UNETT:
+    masks += [("f16 products in: qkv + attention", 7), ("f16 products in: qkv + attention + ff1", 23), ("f16 products in: out + ff2 + skip (the residual writers)", 8 + 32 + 512)]
+masks += [("f16 products in: attn_qk + attn_pv", 6), ("f16 products in: all four block GEMMs", 57), ("f16 products in: the blocks (GEMMs + attention)", 63),
           ("f16 products in: in_proj + conv_pos + proj_out (the I/O layers)", 448), ("f16 products in: blocks + in_proj", 63 + 64),
           ("f16 products in: blocks + conv_pos", 63 + 128), ("f16 products in: blocks + proj_out", 63 + 256), ("f16 products in: everything", 511)]
 for name, mask in masks:
