@@ -39,6 +39,9 @@ template <int OFF> __device__ __forceinline__ void lds_read_b128_off(u32x4& dst,
 __device__ __forceinline__ void reg_fence(u32x4& a) { asm volatile("" : "+v"(a)); }
 
 // DIAG (tools only; 0 in the product): 4 = no epilogue (the K loop + launch alone: what the epilogue of a shape costs by omission)
+// DIAG bit 8 (product, T = float): both operands PRE-SPLIT into f16 hi / lo planes (gemm2.h MODE 5, F5_PREC_F16X3: a 128-byte row is 32
+// elements, chunks 0-3 hi, 4-7 lo, so the two fragment reads of a row ARE hi and lo); a phase is then 24 f16 MFMAs -- per accumulator
+// and K-tile lo x hi, hi x lo, hi x hi, the order of gemm2's MODE 5 (bit-identical results).
 template <typename T, typename Epi, int DIAG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw, int M,
                                                       int N, int K, Epi epi, int xa, int xb, const int* __restrict__ m_limit) {
@@ -132,6 +135,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
         auto mma_quadrant = [&](auto i0c, u32x4 (&bf)[2][2], auto j0c) {   // (compile-time tile origin: acc stays in registers)
             constexpr int i0 = decltype(i0c)::value, j0 = decltype(j0c)::value;
             __builtin_amdgcn_s_setprio(1);
+            if constexpr ((DIAG & 8) != 0) {
+                static_assert(std::is_same_v<T, float>, "pre-split operands are f32 rows of f16 hi / lo planes");
+#pragma unroll
+                for (int term = 0; term < 3; ++term)      // term-major, as gemm2.h MODE 5: (w lo, a hi), (w hi, a lo), (w hi, a hi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const u32x4& wv = bf[j][term == 0 ? 1 : 0];
+                            const u32x4& av = af[i][term == 1 ? 1 : 0];
+                            if (!TR) acc[i0 + i][j0 + j] = Mma<f16_t>::run(wv, av, acc[i0 + i][j0 + j]);
+                            else acc[i0 + i][j0 + j] = Mma<f16_t>::run(av, wv, acc[i0 + i][j0 + j]);
+                        }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -141,6 +158,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
                         if (!TR) acc[i0 + i][j0 + j] = Mma<T>::run(bf[j][kk], af[i][kk], acc[i0 + i][j0 + j]);
                         else acc[i0 + i][j0 + j] = Mma<T>::run(af[i][kk], bf[j][kk], acc[i0 + i][j0 + j]);
                     }
+            }
             __builtin_amdgcn_s_setprio(0);
         };
         auto read_a = [&](unsigned ab0, unsigned ab1, auto half) {   // half = 0: rows 0-63 of the wave tile, 1: rows 64-127
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const T* __restrict__ A, i
         kloop(std::false_type{});
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();          // balances the follower's extra barrier
-    if constexpr (DIAG == 4) {
+    if constexpr ((DIAG & 7) == 4) {
         float sink = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)

@@ -48,9 +48,11 @@ template <typename T, typename Epi>
 inline hipError_t launch_gemm_v2(hipStream_t s, const T* A, int lda, const T* W, int ldw, int M, int N, int K,
                                  const Epi& epi, int cfg, const int* ml = nullptr, const GemmConv& cv = GemmConv{}, int split = 0) {
     if constexpr (std::is_same_v<T, float>) {
-        if (split == 2) {   // both operands pre-split (gemm2.h MODE 5)
+        if (split == 2) {   // both operands pre-split (gemm2.h MODE 5; the ping-pong kernel's DIAG bit 8)
             switch (cfg) {
                 case G3_256x256_PP:
+                    if (cv.tpt == 0 && cv.m_base == 0) return launch_gemm3<T, Epi, 8>(s, A, lda, W, ldw, M, N, K, epi, ml);
+                    [[fallthrough]];
                 case G2_256x128_8W: return launch_gemm2_cfg<T, 256, 128, 4, 2, 3, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
                 case G2_128x192_8W: return launch_gemm2_cfg<T, 128, 192, 2, 4, 3, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
                 case G2_128x128_8W: return launch_gemm2_cfg<T, 128, 128, 2, 4, 4, Epi, 5>(s, A, lda, W, ldw, M, N, K, epi, ml, cv);
@@ -101,19 +103,20 @@ inline hipError_t launch_gemm(hipStream_t s, const T* A, int lda, const T* W, in
     // rounds of 256x128 tiles because the ping-pong kernel's fragment-order epilogue overlapped with nothing.  With the staged
     // row-major epilogue (gemm.h) the ping-pong tile wins there too: tools/block_gemm_time.py, 32,768 rows, out-proj / FF2.)
     const float g3_pen = 0.0f;
-    if (K % KT == 0 && force_cfg == -1 && !m_limit && cv.tpt == 0 && !split && sizeof(T) == 2 && gemm3_epilogue_ok(epi)) {
+    const bool v3_ok = ((sizeof(T) == 2 && !split) || split == 2) && gemm3_epilogue_ok(epi);   // 16-bit operands, or f32 rows of pre-split planes
+    if (K % KT == 0 && force_cfg == -1 && !m_limit && cv.tpt == 0 && v3_ok) {
         const int rem = M % 256, main = M - rem;
         const int cfg_main = (rem > 0 && rem <= 64 && main >= 4096) ? pick_cfg_v2(main, N, true, g3_pen) : -1;
         if (cfg_main == G3_256x256_PP || cfg_main == G2_256x128_8W) {
-            hipError_t e = launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, main, N, K, epi, cfg_main);
+            hipError_t e = launch_gemm_v2<T, Epi>(s, A, lda, W, ldw, main, N, K, epi, cfg_main, nullptr, GemmConv{}, split);
             if (e != hipSuccess) return e;
             GemmConv tail{};
             tail.m_base = main;
-            return launch_gemm_v2<T, Epi>(s, A + (size_t)main * lda, lda, W, ldw, rem, N, K, epi, G2_64x64_4W, nullptr, tail);
+            return launch_gemm_v2<T, Epi>(s, A + (size_t)main * lda, lda, W, ldw, rem, N, K, epi, G2_64x64_4W, nullptr, tail, split);
         }
     }
     if (K % KT == 0 && force_cfg != -2) {
-        int cfg = force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, sizeof(T) == 2 && cv.tpt == 0 && gemm3_epilogue_ok(epi), g3_pen);
+        int cfg = force_cfg >= 0 ? force_cfg : pick_cfg_v2(m_hint > 0 ? m_hint : M, N, v3_ok && cv.tpt == 0, g3_pen);
         // pre-split operands (F5_PREC_F16X3 block GEMMs): three MFMAs per fragment pair shift the balance towards the small tile
         // where both fit in two rounds (2048 x 1024 x {1024, 2048}: 64x64 16.2 / 28.7 us, 128x64 18.0 / 30.8 -- tools/probe/gemm_split_probe.hip)
         if (split == 2 && force_cfg < 0 && cfg == G2_128x64_8W && (long)((M + 63) / 64) * ((N + 63) / 64) <= 512) cfg = G2_64x64_4W;
