@@ -155,8 +155,9 @@ static __global__ void unett_assemble_kernel(const float* __restrict__ h, const 
     }
 }
 // out[r, :] = [x[r, :] | skip[r, :]] converted to T   (unett.py:266: cat((x, skip), dim=-1))
+// planar (T = float, F5_PREC_F16X3): the row is written pre-split (store4_planar) -- the A operand of a MODE 5 / ping-pong GEMM
 template <typename T>
-__global__ void cat2_kernel(const float* __restrict__ x, const float* __restrict__ skip, T* __restrict__ out, long rows, int D) {
+__global__ void cat2_kernel(const float* __restrict__ x, const float* __restrict__ skip, T* __restrict__ out, long rows, int D, int planar = 0) {
     const int d4 = D / 4;
     const long total = rows * 2 * d4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -164,7 +165,7 @@ __global__ void cat2_kernel(const float* __restrict__ x, const float* __restrict
         const long r = i / (2 * d4);
         const float4 v = c < d4 ? reinterpret_cast<const float4*>(x + r * D)[c]
                                 : reinterpret_cast<const float4*>(skip + r * D)[c - d4];
-        store4(out + r * 2 * D + (size_t)c * 4, v.x, v.y, v.z, v.w);
+        store4_at(out + r * 2 * D, c * 4, planar, v.x, v.y, v.z, v.w);
     }
 }
 // pred[b', n, :] = pred_all[b', 1 + n, :]     (unett.py:278: norm_out(x)[:, 1:, :])

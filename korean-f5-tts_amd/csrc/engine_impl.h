@@ -654,16 +654,13 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
             const float* skip = w.skips + (size_t)(c.depth - 1 - l) * rows * D;   // LIFO (skips.pop())
             pr.begin(PC_MISC, s);
             hipLaunchKernelGGL((cat2_kernel<T>), dim3(ew_blocks((long)rows * 2 * D / 4)), dim3(256), 0, s, w.x, skip, w.cat2,
-                               (long)rows, D);
+                               (long)rows, D, pl);   // (F5_PREC_F16X3: pre-split, so that the projection runs on pre-split operands too)
             KCHK();
             pr.end(s);
-            if constexpr (std::is_same_v<T, float>) {
-                if (e->x3_ablate & 512)   // diagnostic: ... and its (unsplit f32) A operand as f16 sees it
-                    hipLaunchKernelGGL(round_f16_kernel, dim3(ew_blocks((long)rows * 2 * D)), dim3(256), 0, s, w.cat2, w.cat2, (long)rows * 2 * D);
-            }
+            ablate_a(512, w.cat2, 2 * D);   // diagnostic: ... and its A operand as plain f16
             pr.begin(PC_GEMM, s, gfl(rows, D, 2 * D));
             HIPCHK(egemm<T>(e, s, w.cat2, 2 * D, bw.skip.w, bw.skip.ldw, rows, D, 2 * D,
-                                  EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}));
+                                  EpiStore<float>{w.x, D, nullptr, F5_ACT_NONE}, -1, nullptr, 0, pl));
             pr.end(s);
         }
         pr.begin(PC_LN, s);
