@@ -105,7 +105,7 @@ def load_checkpoint(model, ckpt_path: str, device: str, dtype=None, use_ema: boo
 
 
 def load_model(model_cls, model_cfg: dict, ckpt_path: str | None, mel_spec_type=mel_spec_type, vocab_file: str = "",
-               ode_method=ode_method, use_ema=True, device="cuda", precision="f16p", **_ignored):
+               ode_method=ode_method, use_ema=True, device="cuda", precision="parity", **_ignored):
     """CFM(transformer=model_cls(**model_cfg, text_num_embeds=vocab_size + 1, mel_dim=100), ...) + load_checkpoint.
     `ckpt_path=None` keeps whatever weights the caller loads afterwards (e.g. init_synthetic())."""
     vocab_char_map, vocab_size = load_vocab(vocab_file) if vocab_file else (None, 256)
