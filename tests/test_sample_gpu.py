@@ -395,3 +395,19 @@ def test_real_speech_prompt_mel_and_harness():
     e_wav = float((torch.from_numpy(wave_out) - wref[0]).abs().max())
     print(f"[harness e2e f32, real prompt] rms {rms:.4f}, prompt {ref_len} frames, total {dur}; mel Linf {e_mel:.3e}, wav Linf {e_wav:.3e}")
     assert wave_out.shape == (wref.shape[-1],) and e_mel < 1e-3 and e_wav < 1e-3
+
+
+@pytest.mark.parametrize("name,expect", [("sample_b1_nfe16", "f16p"), ("sample_unett_b2", "f16x3")])
+def test_default_precision_is_parity_grade_for_the_backbone(name, expect):
+    """A backbone built WITHOUT a precision argument ("parity") must land inside the 1e-3 bar of the reference vectors: DiT resolves
+    to f16p, the E2-TTS UNetT (no AdaLN gates; every GEMM class costs ~1e-3 in plain fp16) to f16x3."""
+    meta, a = load_golden(name)
+    sd = synthetic_weights(meta)
+    cls = P.UNetT if meta.get("backbone", "DiT") == "UNetT" else P.DiT
+    tr = cls(**meta["arch"], text_num_embeds=meta["nvocab"], mel_dim=100)
+    assert tr.precision == expect
+    tr.load_state_dict(sd)
+    out, traj = run_case(meta, a, P.CFM(transformer=tr, mel_spec_module=P.mel.MelSpec()).to(DEV))
+    e = (traj.cpu() - a["traj"]).abs().max().item()
+    print(f"[default precision] {name}: {tr.precision}, traj Linf {e:.3e}")
+    assert e < TOL_PARITY
