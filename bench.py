@@ -393,7 +393,7 @@ def main():
     if args.workload == "c5":
         result["parity_precision"] = "f16x3"   # UNetT has no AdaLN gates: its block products dominate the error
         result["parity_note"] = ("E2-TTS UNetT meets north_star's 1e-3 only with split-f16 products in every block (--precision f16x3: "
-                                 "~640-670 ms per step on one MI355X, profiles/r03_n_bench_c5_f16x3.json; f16p 5.0e-3, bf16 3e-2 at Base size)")
+                                 "~610-640 ms per step on one MI355X, profiles/r03_o_bench_c5_f16x3.json; f16p 5.0e-3, bf16 3e-2 at Base size)")
     result["clocks"] = cw.summary()   # rank 0's GPU during the timed region (None where sysfs does not offer it)
     if world > 1:
         result["rccl_ranks"] = dist.get_world_size()

@@ -228,7 +228,9 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q,
                                                                const T* __restrict__ Vt, T* __restrict__ O, int H,
                                                                int N, int Npad, const int* __restrict__ kv_lens,
                                                                int nbatch_lens, const int* __restrict__ q_lens,
-                                                               const int* __restrict__ o_row_start) {
+                                                               const int* __restrict__ o_row_start, float* __restrict__ Of = nullptr) {
+    // Of (F5_PREC_F16X3, or null): the output as f32 rows PRE-SPLIT into f16 hi / lo planes (store4_planar) -- the A operand of the
+    // out-projection's pre-split GEMM -- instead of T rows in O
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // query blocks wholly past the sample's own length (padded batches): their output rows are zeroed by the reference
     // (modules.py:540-542; here: never read, the out-projection epilogue masks those rows) -- exit before any barrier
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(512) void attn2_fwd_kernel(const T* __restrict__ Q,
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         v[r] = (o[dt][qs][r] * a0 + mb[((dt * 2 + qs) * 4 + r) * 64 + lane] * a1) * inv;
-                    store4(dst + dt * 16, v[0], v[1], v[2], v[3]);
+                    if (Of) store4_planar(Of + orow * (H * 64), h * 64 + g * 4 + dt * 16, v[0], v[1], v[2], v[3]);
+                    else store4(dst + dt * 16, v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -379,7 +382,8 @@ template <> inline float attention_q_scale<bf16_t>() { return (attn2_variant() &
 template <> inline float attention_q_scale<f16_t>() { return attention_q_scale<bf16_t>(); }
 template <typename T>
 inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, const T* Vt, T* O, int Bp, int H,
-                                      int N, int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens, const int* o_row_start) {
+                                      int N, int Npad, const int* kv_lens, int nbatch_lens, const int* q_lens, const int* o_row_start,
+                                      float* o_planar_f32 = nullptr) {
     constexpr int smem = 3 * 2 * 64 * 128;  // 48 KiB ring (>= 4 * 36 * 64 * 4 = 36 KiB merge scratch)
     dim3 grid(Bp * H, (N + 127) / 128);
     const int var = attn2_variant();
@@ -392,7 +396,7 @@ inline hipError_t launch_attention_v2(hipStream_t s, const T* Q, const T* K, con
             if (e != hipSuccess) return e;                                                                             \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((attn2_fwd_kernel<T, V>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start); \
+        hipLaunchKernelGGL((attn2_fwd_kernel<T, V>), grid, dim3(512), smem, s, Q, K, Vt, O, H, N, Npad, kv_lens, nbatch_lens, q_lens, o_row_start, o_planar_f32); \
     }
     if (var == 0) F5_ATTN2_LAUNCH(0)
     else if (var == 3) F5_ATTN2_LAUNCH(3)

@@ -491,10 +491,23 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
         pr.end(s);
         ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gflops(3 * inner, D));
+        // F5_PREC_F16X3 with plain-f16 attention products (x3_attn_hi == 3): q / k / v^T leave the QKV epilogue as f16 and the fast
+        // 16-bit attention kernel writes its output pre-split for the out-projection (the f32 buffers are reused at half their size)
+        bool attn16 = false;
+        if constexpr (std::is_same_v<T, float>) {
+            attn16 = e->split16 && e->x3_attn_hi == 3 && !qk_norm;
+            if (attn16)
+                HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                                EpiQKV<f16_t>{reinterpret_cast<f16_t*>(w.q), reinterpret_cast<f16_t*>(w.k), reinterpret_cast<f16_t*>(w.vt),
+                                              bw.qkv.b, P.rope_frag, N, w.Npad, H, pe_heads, attention_q_scale<f16_t>(), pk.rowmap},
+                                -1, ml, mh, pl));
+        }
+        if (!attn16) {
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_frag, N, w.Npad, H, qk_norm ? 0 : pe_heads,
                                         qk_norm ? 1.0f : attention_q_scale<T>(), pk.rowmap},
                               -1, ml, mh, pl));
+        }
         pr.end(s);
         if (qk_norm) {   // RMSNorm on q / k comes BEFORE the rotary embedding (modules.py:481-497): the epilogue left both raw
             const long qrows = (long)Bp * H * N;
@@ -505,8 +518,16 @@ static int run_dit_forward(f5_engine* e, Work<T>& w, const float* y, const float
             pr.end(s);
         }
         pr.begin(PC_ATTN, s, 4.0 * H * 64 * (pk ? pk.sq_host : (double)Bp * N * N));
+        if constexpr (std::is_same_v<T, float>) {
+            if (attn16)
+                HIPCHK(launch_attention_v2<f16_t>(s, reinterpret_cast<const f16_t*>(w.q), reinterpret_cast<const f16_t*>(w.k),
+                                                  reinterpret_cast<const f16_t*>(w.vt), nullptr, Bp, H, N, w.Npad, attn_lens, B, lens_dev,
+                                                  pk.row_start, reinterpret_cast<float*>(w.ao)));
+        }
+        if (!attn16) {
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, N, w.Npad, attn_lens, B, lens_dev, pk.row_start, e->split16, pl,
                                     e->x3_attn_hi));
+        }
         pr.end(s);
         ablate_a(8, w.ao, inner);
         pr.begin(PC_GEMM, s, gflops(D, inner));
@@ -669,13 +690,32 @@ static int run_unett_forward(f5_engine* e, Work<T>& w, const float* y, const flo
         pr.end(s);
         ablate_a(1, w.xn, D);
         pr.begin(PC_GEMM, s, gfl(rows, 3 * inner, D));
+        bool attn16 = false;   // (run_dit_forward)
+        if constexpr (std::is_same_v<T, float>) {
+            attn16 = e->split16 && e->x3_attn_hi == 3;
+            if (attn16)
+                HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
+                                EpiQKV<f16_t>{reinterpret_cast<f16_t*>(w.q), reinterpret_cast<f16_t*>(w.k), reinterpret_cast<f16_t*>(w.vt),
+                                              bw.qkv.b, P.rope_frag, Nt, w.Npad, H, pe_heads, attention_q_scale<f16_t>()},
+                                -1, nullptr, 0, pl));
+        }
+        if (!attn16) {
         HIPCHK(egemm<T>(e, s, w.xn, D, bw.qkv.w, bw.qkv.ldw, rows, 3 * inner, D,
                               EpiQKV<T>{w.q, w.k, w.vt, bw.qkv.b, P.rope_frag, Nt, w.Npad, H, pe_heads, attention_q_scale<T>()},
                               -1, nullptr, 0, pl));
+        }
         pr.end(s);
         pr.begin(PC_ATTN, s, 4.0 * Bp * H * (double)Nt * Nt * 64);
+        if constexpr (std::is_same_v<T, float>) {
+            if (attn16)
+                HIPCHK(launch_attention_v2<f16_t>(s, reinterpret_cast<const f16_t*>(w.q), reinterpret_cast<const f16_t*>(w.k),
+                                                  reinterpret_cast<const f16_t*>(w.vt), nullptr, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev,
+                                                  nullptr, reinterpret_cast<float*>(w.ao)));
+        }
+        if (!attn16) {
         HIPCHK(launch_attention_any(s, w.q, w.k, w.vt, w.ao, Bp, H, Nt, w.Npad, attn_lens, B, lens_dev, nullptr, e->split16, pl,
                                     e->x3_attn_hi));
+        }
         pr.end(s);
         ablate_a(8, w.ao, inner);
         pr.begin(PC_GEMM, s, gfl(rows, D, inner));
